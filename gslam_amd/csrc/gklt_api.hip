@@ -1,0 +1,561 @@
+// C ABI of libgklt.so: contexts, device-resident pyramids and feature lists, stream/event
+// ordering between pyramid builds and tracker launches, and per-kernel event timing.
+#include <algorithm>
+#include <cstring>
+
+#include "gklt_internal.h"
+
+namespace gklt {
+
+int fix_window(gklt_params *p);  // gklt_host.cpp
+
+// ------------------------------------------------------------------ profiling brackets
+ProfScope::ProfScope(gklt_ctx *c, hipStream_t st, int kid) : ctx(c), s(st), id(kid) {
+  if (!ctx || !ctx->profiling) return;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  auto take = [&]() {
+    hipEvent_t e = nullptr;
+    if (!ctx->free_events.empty()) {
+      e = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+      e = nullptr;
+    }
+    return e;
+  };
+  a = take();
+  b = take();
+  if (a && b) (void)hipEventRecord(a, s);
+}
+
+ProfScope::~ProfScope() {
+  if (!a || !b) return;
+  (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->spans.push_back({a, b, id});
+}
+
+static int fold_spans(gklt_ctx *ctx) {
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (auto &sp : ctx->spans) {
+    float ms = 0.f;
+    GKLT_HIP(hipEventSynchronize(sp.b));
+    GKLT_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+    ctx->prof_ms[sp.id] += ms;
+    ctx->prof_n[sp.id] += 1;
+    ctx->free_events.push_back(sp.a);
+    ctx->free_events.push_back(sp.b);
+  }
+  ctx->spans.clear();
+  return 0;
+}
+
+static int use_device(gklt_ctx *ctx) {
+  GKLT_HIP(hipSetDevice(ctx->device));
+  return 0;
+}
+
+static int ensure_nv(gklt_ctx *ctx, int n) {
+  if (n <= ctx->d_nv_capacity) return 0;
+  if (ctx->d_norm) (void)hipFree(ctx->d_norm);
+  if (ctx->d_vec) (void)hipFree(ctx->d_vec);
+  ctx->d_norm = ctx->d_vec = nullptr;
+  ctx->d_nv_capacity = 0;
+  GKLT_HIP(hipMalloc(&ctx->d_norm, sizeof(double) * 3 * (size_t)n));
+  GKLT_HIP(hipMalloc(&ctx->d_vec, sizeof(double) * 3 * (size_t)n));
+  ctx->d_nv_capacity = n;
+  return 0;
+}
+
+static int check_params(const gklt_params &p) {
+  if (p.nPyramidLevels < 1 || p.nPyramidLevels > GKLT_MAX_LEVELS) {
+    set_error("nPyramidLevels %d outside [1,%d]", p.nPyramidLevels, GKLT_MAX_LEVELS);
+    return GKLT_EINVAL;
+  }
+  if (p.subsampling < 1) {
+    set_error("subsampling %d < 1", p.subsampling);
+    return GKLT_EINVAL;
+  }
+  if (p.window_width > 255 || p.window_height > 255) {
+    set_error("window %dx%d too large", p.window_width, p.window_height);
+    return GKLT_EINVAL;
+  }
+  return 0;
+}
+
+}  // namespace gklt
+
+using namespace gklt;
+
+// ====================================================================== context
+extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
+  if (!out) return GKLT_EINVAL;
+  *out = nullptr;
+  int ndev = 0;
+  GKLT_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    set_error("device %d not present (%d visible): libgklt needs an AMD GPU", device, ndev);
+    return GKLT_EINVAL;
+  }
+  GKLT_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  GKLT_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; libgklt is built for gfx950 only", device, prop.gcnArchName);
+    return GKLT_EINVAL;
+  }
+  gklt_ctx *c = new gklt_ctx();
+  c->device = device;
+  gklt_default_params(&c->prm);
+  GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
+  GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+  GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
+  *out = c;
+  return 0;
+}
+
+extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
+  if (!ctx) return 0;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->s_pyr);
+  (void)hipStreamSynchronize(ctx->s_trk);
+  fold_spans(ctx);
+  for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+  if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
+  (void)hipFree(ctx->d_frame);
+  (void)hipFree(ctx->d_invk);
+  (void)hipFree(ctx->d_norm);
+  (void)hipFree(ctx->d_vec);
+  (void)hipStreamDestroy(ctx->s_pyr);
+  (void)hipStreamDestroy(ctx->s_trk);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int gklt_ctx_set_params(gklt_ctx *ctx, const gklt_params *p) {
+  if (!ctx || !p) return GKLT_EINVAL;
+  gklt_params q = *p;
+  fix_window(&q);  // LK.hpp:982-1013 warn-and-fix (the shim prints the KLTWarning)
+  if (int rc = check_params(q)) return rc;
+  ctx->prm = q;
+  return 0;
+}
+
+extern "C" int gklt_ctx_get_params(gklt_ctx *ctx, gklt_params *p) {
+  if (!ctx || !p) return GKLT_EINVAL;
+  *p = ctx->prm;
+  return 0;
+}
+
+extern "C" int gklt_sync(gklt_ctx *ctx) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipStreamSynchronize(ctx->s_pyr));
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  return 0;
+}
+
+// ====================================================================== pyramid
+extern "C" int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_pyramid **out) {
+  if (!ctx || !out || width < 1 || height < 1) return GKLT_EINVAL;
+  *out = nullptr;
+  if (int rc = use_device(ctx)) return rc;
+  const gklt_params &P = ctx->prm;
+  gklt_pyramid *py = new gklt_pyramid();
+  py->ctx = ctx;
+  py->nlevels = P.nPyramidLevels;
+  py->ss = P.subsampling;
+  int w = width, h = height;
+  for (int l = 0; l < py->nlevels; ++l) {
+    if (w < 1 || h < 1) {
+      set_error("level %d of a %dx%d frame is empty", l, width, height);
+      gklt_pyramid_destroy(py);
+      return GKLT_EINVAL;
+    }
+    py->lv[l].w = w;
+    py->lv[l].h = h;
+    if (hipMalloc(&py->lv[l].img, sizeof(float) * (size_t)w * h) != hipSuccess ||
+        hipMalloc(&py->lv[l].tex, sizeof(Texel) * (size_t)w * h) != hipSuccess) {
+      set_error("hipMalloc of pyramid level %d (%dx%d) failed", l, w, h);
+      gklt_pyramid_destroy(py);
+      return GKLT_ENOMEM;
+    }
+    w /= py->ss;  // pyramid.cpp:64
+    h /= py->ss;
+  }
+  if (hipMalloc(&py->tmp, sizeof(float) * (size_t)width * height) != hipSuccess) {
+    set_error("hipMalloc of pyramid scratch failed");
+    gklt_pyramid_destroy(py);
+    return GKLT_ENOMEM;
+  }
+  GKLT_HIP(hipEventCreateWithFlags(&py->ready, hipEventDisableTiming));
+  GKLT_HIP(hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming));
+  *out = py;
+  return 0;
+}
+
+extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
+  if (!py) return 0;
+  (void)hipSetDevice(py->ctx->device);
+  (void)hipStreamSynchronize(py->ctx->s_pyr);
+  (void)hipStreamSynchronize(py->ctx->s_trk);
+  for (int l = 0; l < GKLT_MAX_LEVELS; ++l) {
+    if (py->lv[l].img) (void)hipFree(py->lv[l].img);
+    if (py->lv[l].tex) (void)hipFree(py->lv[l].tex);
+  }
+  if (py->tmp) (void)hipFree(py->tmp);
+  if (py->ready) (void)hipEventDestroy(py->ready);
+  if (py->consumed) (void)hipEventDestroy(py->consumed);
+  delete py;
+  return 0;
+}
+
+extern "C" int gklt_pyramid_levels(const gklt_pyramid *py) { return py ? py->nlevels : GKLT_EINVAL; }
+
+extern "C" int gklt_pyramid_level_size(const gklt_pyramid *py, int level, int *width, int *height) {
+  if (!py || level < 0 || level >= py->nlevels) return GKLT_EINVAL;
+  if (width) *width = py->lv[level].w;
+  if (height) *height = py->lv[level].h;
+  return 0;
+}
+
+extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t *img, int stride,
+                                  int img_on_device) {
+  if (!ctx || !py || !img || py->ctx != ctx) return GKLT_EINVAL;
+  const gklt_params &P = ctx->prm;
+  const int W = py->lv[0].w, H = py->lv[0].h;
+  if (stride < W) {
+    set_error("stride %d < width %d", stride, W);
+    return GKLT_EINVAL;
+  }
+  if (py->nlevels != P.nPyramidLevels || py->ss != P.subsampling) {
+    set_error("pyramid was created for %d levels / subsampling %d, context now has %d / %d",
+              py->nlevels, py->ss, P.nPyramidLevels, P.subsampling);
+    return GKLT_EINVAL;
+  }
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_pyr;
+
+  // kernels for this call: the reference recomputes them on every call
+  float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
+  int gw, dw;
+  Taps smooth0, pyr, gradg, gradd;
+  if (int rc = gklt_compute_kernels(gklt_compute_smooth_sigma(&P), g, &gw, d, &dw)) return rc;
+  half_taps(g, gw, +1, &smooth0);
+  if (py->nlevels > 1) {
+    if (int rc = gklt_compute_kernels(P.subsampling * P.pyramid_sigma_fact, g, &gw, d, &dw))
+      return rc;  // pyramid.cpp:56
+    half_taps(g, gw, +1, &pyr);
+  }
+  if (int rc = gklt_compute_kernels(P.grad_sigma, g, &gw, d, &dw)) return rc;  // pyramid.cpp:69-71
+  half_taps(g, gw, +1, &gradg);
+  half_taps(d, dw, -1, &gradd);
+
+  // do not overwrite planes a tracker launch may still be reading
+  if (py->has_consumed) GKLT_HIP(hipStreamWaitEvent(s, py->consumed, 0));
+
+  const uint8_t *src = img;
+  int src_stride = stride;
+  if (!img_on_device) {
+    const size_t bytes = (size_t)W * H;
+    if (ctx->d_frame_bytes < bytes) {
+      GKLT_HIP(hipStreamSynchronize(s));
+      if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+      ctx->d_frame = nullptr;
+      ctx->d_frame_bytes = 0;
+      GKLT_HIP(hipMalloc(&ctx->d_frame, bytes));
+      ctx->d_frame_bytes = bytes;
+    }
+    GKLT_HIP(hipMemcpy2DAsync(ctx->d_frame, W, img, stride, W, H, hipMemcpyHostToDevice, s));
+    src = ctx->d_frame;
+    src_stride = W;
+  }
+
+  // pyramid.cpp:59-61  u8 -> f32 -> smooth
+  if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, smooth0, py->lv[0].img)) return rc;
+  for (int l = 1; l < py->nlevels; ++l) {  // pyramid.cpp:62-66
+    const Level &a = py->lv[l - 1], &b = py->lv[l];
+    if (a.w == 2 * b.w && a.h == 2 * b.h) {
+      if (int rc = launch_smooth_decimate2(ctx, s, a.img, a.w, a.h, pyr, b.img, b.w, b.h)) return rc;
+    } else {
+      if (int rc = launch_smooth_f32(ctx, s, a.img, a.w, a.h, pyr, py->tmp, GKLT_K_DOWN)) return rc;
+      if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
+    }
+  }
+  for (int l = 0; l < py->nlevels; ++l) {  // pyramid.cpp:72-83
+    const Level &a = py->lv[l];
+    if (int rc = launch_gradients_tex(ctx, s, a.img, a.w, a.h, gradg, gradd, a.tex)) return rc;
+  }
+  GKLT_HIP(hipEventRecord(py->ready, s));
+  py->has_ready = true;
+  return 0;
+}
+
+extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level, int plane,
+                                     float *dst, int dst_stride) {
+  if (!ctx || !py || !dst || level < 0 || level >= py->nlevels || plane < 0 || plane > 2)
+    return GKLT_EINVAL;
+  const Level &L = py->lv[level];
+  if (dst_stride < L.w) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_pyr;
+  const float *src = L.img;
+  if (plane != 0) {
+    GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+    if (int rc = launch_tex_extract(ctx, s, L.tex, L.w * L.h, plane, py->tmp)) return rc;
+    src = py->tmp;
+  }
+  GKLT_HIP(hipMemcpy2DAsync(dst, sizeof(float) * dst_stride, src, sizeof(float) * L.w,
+                            sizeof(float) * L.w, L.h, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *py, int level, int plane,
+                                   const float *src, int src_stride) {
+  if (!ctx || !py || !src || level < 0 || level >= py->nlevels || plane < 0 || plane > 2)
+    return GKLT_EINVAL;
+  const Level &L = py->lv[level];
+  if (src_stride < L.w) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_pyr;
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  float *stage = plane == 0 ? L.img : py->tmp;
+  GKLT_HIP(hipMemcpy2DAsync(stage, sizeof(float) * L.w, src, sizeof(float) * src_stride,
+                            sizeof(float) * L.w, L.h, hipMemcpyHostToDevice, s));
+  if (int rc = launch_tex_insert(ctx, s, L.tex, L.w * L.h, plane, stage)) return rc;
+  GKLT_HIP(hipEventRecord(py->ready, s));
+  py->has_ready = true;
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// standalone P1 / P2 on host images
+namespace {
+struct DevBuf {
+  float *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" int gklt_smooth(gklt_ctx *ctx, const float *src, int width, int height, float sigma,
+                           float *dst) {
+  if (!ctx || !src || !dst || width < 1 || height < 1) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
+  int gw, dw;
+  if (int rc = gklt_compute_kernels(sigma, g, &gw, d, &dw)) return rc;  // convolve.cpp:50-52
+  Taps tg;
+  half_taps(g, gw, +1, &tg);
+  const size_t bytes = sizeof(float) * (size_t)width * height;
+  DevBuf a, b;
+  GKLT_HIP(hipMalloc(&a.p, bytes));
+  GKLT_HIP(hipMalloc(&b.p, bytes));
+  hipStream_t s = ctx->s_pyr;
+  GKLT_HIP(hipMemcpyAsync(a.p, src, bytes, hipMemcpyHostToDevice, s));
+  if (int rc = launch_smooth_f32(ctx, s, a.p, width, height, tg, b.p, GKLT_K_MISC)) return rc;
+  GKLT_HIP(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int gklt_gradients(gklt_ctx *ctx, const float *src, int width, int height, float sigma,
+                              float *gradx, float *grady) {
+  if (!ctx || !src || !gradx || !grady || width < 1 || height < 1) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
+  int gw, dw;
+  if (int rc = gklt_compute_kernels(sigma, g, &gw, d, &dw)) return rc;  // convolve.cpp:26-28
+  Taps tg, td;
+  half_taps(g, gw, +1, &tg);
+  half_taps(d, dw, -1, &td);
+  const size_t bytes = sizeof(float) * (size_t)width * height;
+  DevBuf a, bx, by;
+  GKLT_HIP(hipMalloc(&a.p, bytes));
+  GKLT_HIP(hipMalloc(&bx.p, bytes));
+  GKLT_HIP(hipMalloc(&by.p, bytes));
+  hipStream_t s = ctx->s_pyr;
+  GKLT_HIP(hipMemcpyAsync(a.p, src, bytes, hipMemcpyHostToDevice, s));
+  if (int rc = launch_gradients_planar(ctx, s, a.p, width, height, tg, td, bx.p, by.p)) return rc;
+  GKLT_HIP(hipMemcpyAsync(gradx, bx.p, bytes, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipMemcpyAsync(grady, by.p, bytes, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ====================================================================== feature lists
+extern "C" int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out) {
+  if (!ctx || !out || capacity < 1) return GKLT_EINVAL;
+  *out = nullptr;
+  if (int rc = use_device(ctx)) return rc;
+  gklt_flist *fl = new gklt_flist();
+  fl->ctx = ctx;
+  fl->capacity = capacity;
+  if (hipMalloc(&fl->x, sizeof(float) * capacity) != hipSuccess ||
+      hipMalloc(&fl->y, sizeof(float) * capacity) != hipSuccess ||
+      hipMalloc(&fl->val, sizeof(int) * capacity) != hipSuccess ||
+      hipMalloc(&fl->stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
+    set_error("hipMalloc of a %d-feature list failed", capacity);
+    gklt_flist_destroy(fl);
+    return GKLT_ENOMEM;
+  }
+  GKLT_HIP(hipMemsetAsync(fl->stats, 0, 2 * sizeof(unsigned long long), ctx->s_trk));
+  *out = fl;
+  return 0;
+}
+
+extern "C" int gklt_flist_destroy(gklt_flist *fl) {
+  if (!fl) return 0;
+  (void)hipSetDevice(fl->ctx->device);
+  (void)hipStreamSynchronize(fl->ctx->s_trk);
+  (void)hipFree(fl->x);
+  (void)hipFree(fl->y);
+  (void)hipFree(fl->val);
+  (void)hipFree(fl->stats);
+  delete fl;
+  return 0;
+}
+
+extern "C" int gklt_flist_size(const gklt_flist *fl) { return fl ? fl->n : GKLT_EINVAL; }
+
+extern "C" int gklt_flist_upload(gklt_ctx *ctx, gklt_flist *fl, int n, const float *x,
+                                 const float *y, const int *val) {
+  if (!ctx || !fl || n < 0 || (n > 0 && (!x || !y || !val))) return GKLT_EINVAL;
+  if (n > fl->capacity) {
+    set_error("%d features exceed the list capacity %d", n, fl->capacity);
+    return GKLT_ECAPACITY;
+  }
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_trk;
+  if (n > 0) {
+    GKLT_HIP(hipMemcpyAsync(fl->x, x, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipMemcpyAsync(fl->y, y, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipMemcpyAsync(fl->val, val, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  }
+  fl->n = n;
+  return 0;
+}
+
+extern "C" int gklt_flist_download_async(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y,
+                                         int *val) {
+  if (!ctx || !fl) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_trk;
+  const int n = fl->n;
+  if (n == 0) return 0;
+  if (x) GKLT_HIP(hipMemcpyAsync(x, fl->x, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (y) GKLT_HIP(hipMemcpyAsync(y, fl->y, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  if (val) GKLT_HIP(hipMemcpyAsync(val, fl->val, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+extern "C" int gklt_flist_download(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y, int *val) {
+  if (int rc = gklt_flist_download_async(ctx, fl, x, y, val)) return rc;
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  return 0;
+}
+
+extern "C" int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked,
+                                uint64_t *iterations, int reset) {
+  if (!ctx || !fl) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  unsigned long long h[2];
+  GKLT_HIP(hipMemcpyAsync(h, fl->stats, sizeof h, hipMemcpyDeviceToHost, ctx->s_trk));
+  if (reset) GKLT_HIP(hipMemsetAsync(fl->stats, 0, sizeof h, ctx->s_trk));
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  if (tracked) *tracked = h[0];
+  if (iterations) *iterations = h[1];
+  return 0;
+}
+
+// ====================================================================== tracker
+static int track_common(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2, int n, float *dx,
+                        float *dy, int *dval, const double *d_invk, double *d_norm, double *d_vec,
+                        unsigned long long *stats) {
+  hipStream_t s = ctx->s_trk;
+  if (!p1->has_ready || !p2->has_ready) {
+    set_error("tracking on a pyramid that was never built");
+    return GKLT_EINVAL;
+  }
+  GKLT_HIP(hipStreamWaitEvent(s, p1->ready, 0));
+  GKLT_HIP(hipStreamWaitEvent(s, p2->ready, 0));
+  if (int rc = launch_track(ctx, s, p1, p2, n, dx, dy, dval, d_invk, d_norm, d_vec, stats))
+    return rc;
+  GKLT_HIP(hipEventRecord(p1->consumed, s));
+  p1->has_consumed = true;
+  if (p2 != p1) {
+    GKLT_HIP(hipEventRecord(p2->consumed, s));
+    p2->has_consumed = true;
+  }
+  return 0;
+}
+
+extern "C" int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2,
+                                gklt_flist *fl) {
+  if (!ctx || !p1 || !p2 || !fl || p1->ctx != ctx || p2->ctx != ctx || fl->ctx != ctx)
+    return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  return track_common(ctx, p1, p2, fl->n, fl->x, fl->y, fl->val, nullptr, nullptr, nullptr,
+                      fl->stats);
+}
+
+extern "C" int gklt_track(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2, int n, float *x,
+                          float *y, int *val, const double *invK, double *norm3, double *vec3) {
+  if (!ctx || !p1 || !p2 || p1->ctx != ctx || p2->ctx != ctx || n < 0) return GKLT_EINVAL;
+  if (n == 0) return 0;
+  if (!x || !y || !val) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  if (!ctx->scratch_list || ctx->scratch_list->capacity < n) {
+    if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
+    ctx->scratch_list = nullptr;
+    if (int rc = gklt_flist_create(ctx, std::max(n, 4096), &ctx->scratch_list)) return rc;
+  }
+  gklt_flist *fl = ctx->scratch_list;
+  hipStream_t s = ctx->s_trk;
+  if (int rc = gklt_flist_upload(ctx, fl, n, x, y, val)) return rc;
+  const bool epi = invK && norm3 && vec3;
+  if (epi) {
+    if (int rc = ensure_nv(ctx, n)) return rc;
+    GKLT_HIP(hipMemcpyAsync(ctx->d_invk, invK, 9 * sizeof(double), hipMemcpyHostToDevice, s));
+    // untracked entries keep the caller's contents: round-trip them
+    GKLT_HIP(hipMemcpyAsync(ctx->d_norm, norm3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipMemcpyAsync(ctx->d_vec, vec3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+  }
+  if (int rc = track_common(ctx, p1, p2, n, fl->x, fl->y, fl->val, epi ? ctx->d_invk : nullptr,
+                            epi ? ctx->d_norm : nullptr, epi ? ctx->d_vec : nullptr, nullptr))
+    return rc;
+  GKLT_HIP(hipMemcpyAsync(x, fl->x, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipMemcpyAsync(y, fl->y, sizeof(float) * n, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipMemcpyAsync(val, fl->val, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  if (epi) {
+    GKLT_HIP(hipMemcpyAsync(norm3, ctx->d_norm, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipMemcpyAsync(vec3, ctx->d_vec, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
+  }
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ====================================================================== measurement
+extern "C" int gklt_profile_enable(gklt_ctx *ctx, int on) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = gklt_sync(ctx)) return rc;
+  ctx->profiling = on != 0;
+  return 0;
+}
+
+extern "C" int gklt_profile_get(gklt_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches) {
+  if (!ctx || kernel_id < 0 || kernel_id >= GKLT_K_COUNT) return GKLT_EINVAL;
+  if (int rc = gklt_sync(ctx)) return rc;
+  if (int rc = fold_spans(ctx)) return rc;
+  if (total_ms) *total_ms = ctx->prof_ms[kernel_id];
+  if (launches) *launches = ctx->prof_n[kernel_id];
+  return 0;
+}
+
+extern "C" int gklt_profile_reset(gklt_ctx *ctx) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = gklt_sync(ctx)) return rc;
+  if (int rc = fold_spans(ctx)) return rc;
+  for (int i = 0; i < GKLT_K_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+  return 0;
+}

@@ -1,0 +1,125 @@
+// Internal declarations shared by the translation units of libgklt.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/gklt.h"
+
+namespace gklt {
+
+void set_error(const char *fmt, ...);
+#define GKLT_HIP(call)                                                                     \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      gklt::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
+                      __LINE__);                                                           \
+      return GKLT_EHIP;                                                                    \
+    }                                                                                      \
+  } while (0)
+
+// Half of a symmetric (sym=+1) or antisymmetric (sym=-1) convolution kernel:
+// k[0] = centre tap, k[j] = tap at offset +j (tap at -j is sym*k[j]).
+constexpr int kMaxRadius = GKLT_MAX_KERNEL_WIDTH / 2;  // 35
+struct Taps {
+  int r;
+  int sym;
+  float k[kMaxRadius + 1];
+};
+
+// One pixel of a pyramid level as the tracker reads it: (I, gx, gy, 0).
+using Texel = float4;
+
+struct Level {
+  int w = 0, h = 0;
+  float *img = nullptr;  // planar I, w*h
+  Texel *tex = nullptr;  // interleaved (I, gx, gy, 0), w*h
+};
+
+}  // namespace gklt
+
+struct gklt_ctx {
+  int device = 0;
+  gklt_params prm{};
+  hipStream_t s_pyr = nullptr;  // pyramid builds
+  hipStream_t s_trk = nullptr;  // tracker, feature list copies
+  // staging for host frames / host feature lists (grown on demand)
+  uint8_t *d_frame = nullptr;
+  size_t d_frame_bytes = 0;
+  gklt_flist *scratch_list = nullptr;
+  double *d_invk = nullptr;  // 9 doubles
+  double *d_norm = nullptr, *d_vec = nullptr;
+  int d_nv_capacity = 0;
+  // profiling
+  bool profiling = false;
+  struct Span {
+    hipEvent_t a, b;
+    int id;
+  };
+  std::mutex mu;
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> free_events;
+  double prof_ms[GKLT_K_COUNT] = {};
+  int64_t prof_n[GKLT_K_COUNT] = {};
+};
+
+struct gklt_pyramid {
+  gklt_ctx *ctx = nullptr;
+  int nlevels = 0, ss = 2;
+  gklt::Level lv[GKLT_MAX_LEVELS];
+  float *tmp = nullptr;      // level-0-sized scratch plane (generic resize path, plane download)
+  hipEvent_t ready = nullptr;     // recorded on s_pyr after a build
+  hipEvent_t consumed = nullptr;  // recorded on s_trk after a tracker launch that read it
+  bool has_ready = false, has_consumed = false;
+};
+
+struct gklt_flist {
+  gklt_ctx *ctx = nullptr;
+  int capacity = 0, n = 0;
+  float *x = nullptr, *y = nullptr;
+  int *val = nullptr;
+  unsigned long long *stats = nullptr;  // [0] tracked, [1] iterations
+};
+
+namespace gklt {
+
+// RAII-less profiling bracket: call begin() before and end() after the launch.
+struct ProfScope {
+  gklt_ctx *ctx;
+  hipStream_t s;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(gklt_ctx *c, hipStream_t st, int kid);
+  ~ProfScope();
+};
+
+int half_taps(const float *full, int width, int sym, Taps *out);
+int fix_window(gklt_params *p);
+
+// pyramid kernels (gklt_pyramid.hip)
+int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,
+                     const Taps &g, float *dst);
+int launch_smooth_f32(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h, const Taps &g,
+                      float *dst, int prof_id);
+int launch_smooth_decimate2(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
+                            const Taps &g, float *dst, int w2, int h2);
+int launch_resize_linear(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h, float *dst,
+                         int w2, int h2);
+int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
+                         const Taps &g, const Taps &d, Texel *tex);
+int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
+                            const Taps &g, const Taps &d, float *gx, float *gy);
+int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);
+int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp, const float *src);
+
+// tracker (gklt_track.hip)
+int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gklt_pyramid *p2,
+                 int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
+                 double *d_vec, unsigned long long *stats);
+
+}  // namespace gklt

@@ -1,0 +1,346 @@
+// Coarse-to-fine iterative Lucas-Kanade for gfx950 -- replaces KLTTrackFeatures / KLTInvoker /
+// _trackFeature and the AVX helpers under them (LK.hpp:56-208, 413-669, 825-1046).
+//
+// Mapping: one feature per 8-lane slice of a wavefront (8 features per wave64).  Lane k of a
+// slice owns window elements k, k+8, k+16, ... in row-major window order -- exactly the
+// elements AVX lane k accumulates in the reference (LK.hpp:127-166) -- so each lane's partial
+// sum is built in the reference's order, and the 8 partials are then added left to right
+// (LK.hpp:143-145,163-164,207) after a cross-lane exchange inside the slice.  With the
+// translation unit built -ffp-contract=off every fp32 operation rounds as the reference's
+// unfused AVX code does, which makes positions and status flags reproducible bit for bit.
+//
+// All pyramid levels and all Newton iterations of a feature run inside one launch.  The
+// template patch (I, gx, gy of frame 1) lives in registers for the instantiated window sizes
+// and in LDS for the generic kernel.  Each bilinear tap is one 16-byte load of an (I,gx,gy,0)
+// texel (layout written by gklt_pyramid.hip).
+#include "gklt_internal.h"
+
+namespace gklt {
+
+namespace {
+
+struct TrackLevel {
+  const Texel *t1;
+  const Texel *t2;
+  int nc, nr;
+};
+
+struct TrackArgs {
+  TrackLevel lv[GKLT_MAX_LEVELS];
+  int nlevels;
+  float ss;
+  int ww, wh;
+  float step_factor, min_det, min_disp, max_residue;
+  int max_iter;
+  int w0, h0, borderx, bordery;
+  int n;
+  int do_epilogue;
+};
+
+constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
+
+struct Bilin {
+  int xt, yt;
+  float w0, w1, w2, w3;
+};
+
+// computeBilinearWeight, LK.hpp:56-68: truncating coordinates, three weights formed in double.
+__device__ __forceinline__ Bilin bilinear_weight(float x, float y) {
+  Bilin b;
+  b.xt = (int)x;
+  b.yt = (int)y;
+  const float ax = x - b.xt, ay = y - b.yt;
+  b.w0 = (float)((1.0 - ax) * (1.0 - ay));
+  b.w1 = (float)((ax) * (1.0 - ay));
+  b.w2 = (float)((1.0 - ax) * ay);
+  b.w3 = ax * ay;
+  return b;
+}
+
+// One window element of computeBilinearPatch (LK.hpp:71-108) for all three planes at once.
+__device__ __forceinline__ float3 sample(const Texel *__restrict__ base, int nc, const Bilin &b,
+                                         bool copy_path) {
+  const Texel t00 = base[0], t01 = base[1], t10 = base[nc], t11 = base[nc + 1];
+  if (copy_path) return make_float3(t00.x, t00.y, t00.z);  // LK.hpp:80-85 memcpy rows
+  float3 o;
+  o.x = (t00.x * b.w0 + t01.x * b.w1) + (t10.x * b.w2 + t11.x * b.w3);
+  o.y = (t00.y * b.w0 + t01.y * b.w1) + (t10.y * b.w2 + t11.y * b.w3);
+  o.z = (t00.z * b.w0 + t01.z * b.w1) + (t10.z * b.w2 + t11.z * b.w3);
+  return o;
+}
+
+__device__ __forceinline__ float sample_i(const Texel *__restrict__ base, int nc, const Bilin &b,
+                                          bool copy_path) {
+  const float p00 = base[0].x, p01 = base[1].x, p10 = base[nc].x, p11 = base[nc + 1].x;
+  if (copy_path) return p00;
+  return (p00 * b.w0 + p01 * b.w1) + (p10 * b.w2 + p11 * b.w3);
+}
+
+// lanes 0..7 of the slice added left to right; every lane of the slice gets the total.
+__device__ __forceinline__ float slice_sum(float v) {
+  float t = __shfl(v, 0, SL);
+#pragma unroll
+  for (int j = 1; j < SL; ++j) t = t + __shfl(v, j, SL);
+  return t;
+}
+
+// The bounds test of LK.hpp:558-561 / :620-621 for one point, written so that a NaN coordinate
+// counts as out of bounds (the reference would index memory with it).
+__device__ __forceinline__ bool window_oob(float x, float y, int hw, int hh, int nc, int nr) {
+  const float eps1 = 1.001f;
+  return !(x - hw >= 0.0f) || !(nc - (x + hw) >= eps1) || !(y - hh >= 0.0f) ||
+         !(nr - (y + hh) >= eps1);
+}
+
+// Keeps the 2x2 footprint of every tap inside the plane even if the float bounds test were to
+// admit a window touching the last column/row (cannot change a result the test allows).
+__device__ __forceinline__ void clamp_origin(Bilin &b, int hw, int hh, int nc, int nr) {
+  b.xt = min(max(b.xt, hw), nc - 2 - hw);
+  b.yt = min(max(b.yt, hh), nr - 2 - hh);
+}
+
+// WW,WH > 0: compile-time window, template patch in registers.
+// WW == 0 : run-time window, template patch in LDS ([plane][element][lane]).
+template <int WW, int WH>
+__global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ fx,
+                                              float *__restrict__ fy, int *__restrict__ fval,
+                                              const double *__restrict__ invk,
+                                              double *__restrict__ norm3,
+                                              double *__restrict__ vec3,
+                                              unsigned long long *__restrict__ stats) {
+  constexpr bool kStatic = WW > 0;
+  const int ww = kStatic ? WW : a.ww, wh = kStatic ? WH : a.wh;
+  const int npix = ww * wh;
+  const int ne = (npix + SL) / SL;  // alignedPatchSize / 8 (LK.hpp:448)
+  constexpr int NE = kStatic ? (WW * WH + SL) / SL : 1;
+  const int hw = ww / 2, hh = wh / 2;
+
+  extern __shared__ __align__(16) float lds[];  // generic kernel only: 3 * ne * 64 floats
+  float P1[NE], GX1[NE], GY1[NE];
+
+  const int lane = threadIdx.x;
+  const int k = lane & (SL - 1);
+  const int f = blockIdx.x * (64 / SL) + (lane >> 3);
+  const bool alive = f < a.n && fval[f] >= 0;  // LK.hpp:830
+
+  float xloc = 0.f, yloc = 0.f;
+  if (alive) { xloc = fx[f]; yloc = fy[f]; }
+  for (int r = 0; r < a.nlevels; ++r) { xloc /= a.ss; yloc /= a.ss; }  // LK.hpp:837-839
+  float xo = xloc, yo = yloc;
+  int v = GKLT_TRACKED;
+  int iters_total = 0;
+  bool descending = alive;
+
+  for (int r = a.nlevels - 1; r >= 0; --r) {  // LK.hpp:859-881
+    xloc *= a.ss; yloc *= a.ss;
+    xo *= a.ss; yo *= a.ss;
+    if (!descending) continue;
+
+    // ---- _trackFeature, LK.hpp:413-669 ----
+    const TrackLevel L = a.lv[r];
+    const int nc = L.nc, nr = L.nr;
+    int status = GKLT_TRACKED, iteration = 0;
+    const float x1 = xloc, y1 = yloc;
+    float x2 = xo, y2 = yo;
+
+    if (window_oob(x1, y1, hw, hh, nc, nr) || window_oob(x2, y2, hw, hh, nc, nr)) {
+      status = GKLT_OOB;  // first pass of the do-loop, :558-564
+    } else {
+      // template patches of frame 1 (:467-476; sampled after the bounds test)
+      Bilin b1 = bilinear_weight(x1, y1);
+      clamp_origin(b1, hw, hh, nc, nr);
+      const bool copy1 = b1.w0 == 1.0f;
+      const Texel *o1 = L.t1 + (size_t)(b1.yt - hh) * nc + (b1.xt - hw);
+      if constexpr (kStatic) {
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int i = e * SL + k;
+          float3 s = make_float3(0.f, 0.f, 0.f);
+          if (i < WW * WH) s = sample(o1 + (i / WW) * nc + (i % WW), nc, b1, copy1);
+          P1[e] = s.x; GX1[e] = s.y; GY1[e] = s.z;
+        }
+      } else {
+        for (int e = 0; e < ne; ++e) {
+          const int i = e * SL + k;
+          float3 s = make_float3(0.f, 0.f, 0.f);
+          if (i < npix) s = sample(o1 + (i / ww) * nc + (i % ww), nc, b1, copy1);
+          lds[(0 * ne + e) * 64 + lane] = s.x;
+          lds[(1 * ne + e) * 64 + lane] = s.y;
+          lds[(2 * ne + e) * 64 + lane] = s.z;
+        }
+      }
+
+      float dx, dy;
+      for (;;) {
+        Bilin b2 = bilinear_weight(x2, y2);  // :568-572
+        clamp_origin(b2, hw, hh, nc, nr);
+        const bool copy2 = b2.w0 == 1.0f;
+        const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        float axx = 0.f, ayy = 0.f, axy = 0.f, aex = 0.f, aey = 0.f;
+        auto accumulate = [&](int e, float p1, float g1x, float g1y) {
+          const int i = e * SL + k;
+          float3 s = make_float3(0.f, 0.f, 0.f);
+          if (i < npix) s = sample(o2 + (i / ww) * nc + (i % ww), nc, b2, copy2);
+          const float diff = p1 - s.x;   // computeImageDiff :110-116
+          const float gx = g1x + s.y;    // computeImageSum  :118-125
+          const float gy = g1y + s.z;
+          axx = axx + gx * gx;           // compute2X2GradientMatrix :127-146
+          ayy = ayy + gy * gy;
+          axy = axy + gx * gy;
+          aex = aex + gx * diff;         // compute2X1ErrorVector :148-166
+          aey = aey + gy * diff;
+        };
+        if constexpr (kStatic) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) accumulate(e, P1[e], GX1[e], GY1[e]);
+        } else {
+          for (int e = 0; e < ne; ++e)
+            accumulate(e, lds[(0 * ne + e) * 64 + lane], lds[(1 * ne + e) * 64 + lane],
+                       lds[(2 * ne + e) * 64 + lane]);
+        }
+        const float gxx = slice_sum(axx), gyy = slice_sum(ayy), gxy = slice_sum(axy);
+        const float ex = slice_sum(aex) * a.step_factor, ey = slice_sum(aey) * a.step_factor;
+
+        const float det = gxx * gyy - gxy * gxy;  // _solveEquation :168-183
+        if (det < a.min_det) { status = GKLT_SMALL_DET; break; }
+        dx = (gyy * ex - gxy * ey) / det;
+        dy = (gxx * ey - gxy * ex) / det;
+        status = GKLT_TRACKED;
+        x2 += dx; y2 += dy;
+        ++iteration;
+        if (!((fabsf(dx) >= a.min_disp || fabsf(dy) >= a.min_disp) && iteration < a.max_iter))
+          break;  // :615
+        if (window_oob(x2, y2, hw, hh, nc, nr)) { status = GKLT_OOB; break; }  // next pass :558
+      }
+
+      if (window_oob(x2, y2, hw, hh, nc, nr)) status = GKLT_OOB;  // :620-623
+
+      if (status == GKLT_TRACKED) {  // residue, :626-636
+        Bilin b2 = bilinear_weight(x2, y2);
+        clamp_origin(b2, hw, hh, nc, nr);
+        const bool copy2 = b2.w0 == 1.0f;
+        const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        float asum = 0.f;
+        auto accumulate = [&](int e, float p1) {
+          const int i = e * SL + k;
+          float s = 0.f;
+          if (i < npix) s = sample_i(o2 + (i / ww) * nc + (i % ww), nc, b2, copy2);
+          asum = asum + fabsf(p1 - s);  // computeABSImageDiff :193-208
+        };
+        if constexpr (kStatic) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) accumulate(e, P1[e]);
+        } else {
+          for (int e = 0; e < ne; ++e) accumulate(e, lds[(0 * ne + e) * 64 + lane]);
+        }
+        if (slice_sum(asum) / (ww * wh) > a.max_residue) status = GKLT_LARGE_RESIDUE;
+      }
+    }
+    iters_total += iteration;
+    xo = x2; yo = y2;
+    // return value precedence, :655-667
+    if (status == GKLT_SMALL_DET || status == GKLT_OOB || status == GKLT_LARGE_RESIDUE) v = status;
+    else v = iteration >= a.max_iter ? GKLT_MAX_ITERATIONS : GKLT_TRACKED;
+    if (v == GKLT_SMALL_DET || v == GKLT_OOB) descending = false;  // :879-880
+  }
+
+  // ---- record feature, LK.hpp:886-915 ----
+  bool tracked = false;
+  if (alive) {
+    const bool oob = xo < a.borderx || xo > a.w0 - 1 - a.borderx || yo < a.bordery ||
+                     yo > a.h0 - 1 - a.bordery;  // _outOfBounds :185-191
+    int out;
+    if (v == GKLT_OOB) out = GKLT_OOB;
+    else if (oob) out = GKLT_OOB;
+    else out = v;
+    tracked = out == GKLT_TRACKED;
+    if (k == 0) {
+      fx[f] = tracked ? xo : -1.0f;
+      fy[f] = tracked ? yo : -1.0f;
+      fval[f] = out;
+      if (tracked && a.do_epilogue) {  // bearing vectors, LK.hpp:1019-1035 (fp64)
+        const double px = (double)xo, py = (double)yo;
+        double q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) q[i] = (invk[3 * i] * px + invk[3 * i + 1] * py) + invk[3 * i + 2];
+        const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+        double nv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { nv[i] = q[i] / nn; norm3[3 * (size_t)f + i] = nv[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) vec3[3 * (size_t)f + i] = nv[i] / nv[2];
+      }
+    }
+  }
+  if (stats) {  // one pair of atomics per wave
+    const unsigned long long m = __ballot(tracked && k == 0);
+    int it = (alive && k == 0) ? iters_total : 0;
+#pragma unroll
+    for (int o = 32; o >= SL; o >>= 1) it += __shfl_xor(it, o);
+    if (lane == 0) {
+      atomicAdd(&stats[0], (unsigned long long)__popcll(m));
+      atomicAdd(&stats[1], (unsigned long long)it);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gklt_pyramid *p2,
+                 int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
+                 double *d_vec, unsigned long long *stats) {
+  const gklt_params &P = ctx->prm;
+  if (p1->nlevels != P.nPyramidLevels || p2->nlevels != P.nPyramidLevels ||
+      p1->ss != P.subsampling || p2->ss != P.subsampling) {
+    set_error("pyramids were built for %d levels / subsampling %d, context has %d / %d",
+              p1->nlevels, p1->ss, P.nPyramidLevels, P.subsampling);
+    return GKLT_EINVAL;
+  }
+  TrackArgs a{};
+  for (int l = 0; l < P.nPyramidLevels; ++l) {
+    if (p1->lv[l].w != p2->lv[l].w || p1->lv[l].h != p2->lv[l].h) {
+      set_error("pyramid sizes differ at level %d", l);
+      return GKLT_EINVAL;
+    }
+    a.lv[l] = TrackLevel{p1->lv[l].tex, p2->lv[l].tex, p1->lv[l].w, p1->lv[l].h};
+  }
+  a.nlevels = P.nPyramidLevels;
+  a.ss = (float)P.subsampling;  // LK.hpp:978
+  a.ww = P.window_width;
+  a.wh = P.window_height;
+  a.step_factor = P.step_factor;
+  a.min_det = P.min_determinant;
+  a.min_disp = P.min_displacement;
+  a.max_residue = P.max_residue;
+  a.max_iter = P.max_iterations;
+  a.w0 = p1->lv[0].w;
+  a.h0 = p1->lv[0].h;
+  a.borderx = P.borderx;
+  a.bordery = P.bordery;
+  a.n = n;
+  a.do_epilogue = d_invk && d_norm && d_vec;
+  if (n <= 0) return 0;
+
+  const dim3 grid((n + 7) / 8), block(64);
+  ProfScope ps(ctx, s, GKLT_K_TRACK);
+  if (a.ww == 7 && a.wh == 7) {
+    hipLaunchKernelGGL((k_track<7, 7>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+  } else if (a.ww == 11 && a.wh == 11) {
+    hipLaunchKernelGGL((k_track<11, 11>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+  } else {
+    const int ne = (a.ww * a.wh + 8) / 8;
+    const size_t lds = (size_t)3 * ne * 64 * sizeof(float);
+    if (lds > 160 * 1024) {
+      set_error("window %dx%d needs %zu bytes of LDS per wave (> 160 KiB)", a.ww, a.wh, lds);
+      return GKLT_EINVAL;
+    }
+    if (lds > 48 * 1024)
+      GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_track<0, 0>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_track<0, 0>), grid, block, lds, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+  }
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace gklt

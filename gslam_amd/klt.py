@@ -1,0 +1,296 @@
+"""Thin ctypes binding of libgklt.so (include/gklt.h), named after the reference's entry points.
+
+This is harness plumbing for tests and bench.py; the product is the C ABI.  The reference's host
+API is C++ (KLT.h / KLTUtil.h / pyramid.h / convolve.h / LK.hpp); INTEGRATION.md shows the C++
+shim.  There is no CPU fallback here: if libgklt.so is missing or no gfx950 GPU is present the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgklt.so")
+
+KLT_TRACKED, KLT_NOT_FOUND, KLT_SMALL_DET = 0, -1, -2
+KLT_MAX_ITERATIONS, KLT_OOB, KLT_LARGE_RESIDUE = -3, -4, -5
+K_SMOOTH0, K_DOWN, K_GRAD, K_TRACK, K_MISC = range(5)
+KERNEL_NAMES = {K_SMOOTH0: "smooth0", K_DOWN: "down", K_GRAD: "grad", K_TRACK: "track", K_MISC: "misc"}
+
+
+class GkltError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """gklt_params == the KLT_TrackingContextRec fields the path reads (KLT.h:18-67)."""
+
+    _fields_ = [
+        ("mindist", C.c_int),
+        ("window_width", C.c_int),
+        ("window_height", C.c_int),
+        ("min_eigenvalue", C.c_int),
+        ("min_determinant", C.c_float),
+        ("min_displacement", C.c_float),
+        ("max_iterations", C.c_int),
+        ("max_residue", C.c_float),
+        ("grad_sigma", C.c_float),
+        ("smooth_sigma_fact", C.c_float),
+        ("pyramid_sigma_fact", C.c_float),
+        ("step_factor", C.c_float),
+        ("nSkippedPixels", C.c_int),
+        ("borderx", C.c_int),
+        ("bordery", C.c_int),
+        ("nPyramidLevels", C.c_int),
+        ("subsampling", C.c_int),
+    ]
+
+    def copy(self):
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        return q
+
+
+_lib = None
+
+
+def lib():
+    """Loads libgklt.so; raises if it has not been built (python -m gslam_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GkltError("%s not built: run `python gslam_amd/build.py`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gklt_last_error.restype = C.c_char_p
+        L.gklt_compute_smooth_sigma.restype = C.c_float
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise GkltError("gklt error %d: %s" % (rc, lib().gklt_last_error().decode()))
+    return rc
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+# ---- host-only context arithmetic (KLTUtil.h:12-16) -----------------------------------------
+
+def KLTCreateTrackingContext():
+    p = Params()
+    _check(lib().gklt_default_params(C.byref(p)))
+    return p
+
+
+def KLTChangeTCPyramid(p, search_range):
+    n = C.c_int()
+    _check(lib().gklt_change_tc_pyramid(C.byref(p), int(search_range), C.byref(n)))
+    return n.value
+
+
+def KLTUpdateTCBorder(p):
+    _check(lib().gklt_update_tc_border(C.byref(p)))
+    return p.borderx
+
+
+def computeKernels(sigma):
+    g = np.zeros(71, np.float32)
+    d = np.zeros(71, np.float32)
+    gw, dw = C.c_int(), C.c_int()
+    _check(lib().gklt_compute_kernels(C.c_float(sigma), _fp(g), C.byref(gw), _fp(d), C.byref(dw)))
+    return g[: gw.value].copy(), d[: dw.value].copy()
+
+
+def _KLTComputeSmoothSigma(p):
+    return lib().gklt_compute_smooth_sigma(C.byref(p))
+
+
+def KLTCountRemainingFeatures(val):
+    val = np.ascontiguousarray(val, np.int32)
+    return lib().gklt_count_remaining(len(val), _ip(val))
+
+
+def make_params(window=7, levels=4, subsampling=2, border=None, **kw):
+    """Defaults, then the overrides System.cpp:101-109 applies, then the default border."""
+    p = KLTCreateTrackingContext()
+    p.window_width = p.window_height = window
+    p.nPyramidLevels = levels
+    p.subsampling = subsampling
+    for k, v in kw.items():
+        setattr(p, k, v)
+    if border is None:
+        KLTUpdateTCBorder(p)
+    else:
+        p.borderx = p.bordery = border
+    return p
+
+
+# ---- device objects --------------------------------------------------------------------------
+
+class Context:
+    def __init__(self, device=0, params=None):
+        self.h = C.c_void_p()
+        _check(lib().gklt_ctx_create(int(device), C.byref(self.h)))
+        self.device = device
+        if params is not None:
+            self.set_params(params)
+
+    def set_params(self, p):
+        _check(lib().gklt_ctx_set_params(self.h, C.byref(p)))
+
+    def get_params(self):
+        p = Params()
+        _check(lib().gklt_ctx_get_params(self.h, C.byref(p)))
+        return p
+
+    def sync(self):
+        _check(lib().gklt_sync(self.h))
+
+    def close(self):
+        if self.h:
+            lib().gklt_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    # measurement
+    def profile_enable(self, on=True):
+        _check(lib().gklt_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        _check(lib().gklt_profile_reset(self.h))
+
+    def profile_get(self):
+        out = {}
+        for k, name in KERNEL_NAMES.items():
+            ms, n = C.c_double(), C.c_int64()
+            _check(lib().gklt_profile_get(self.h, k, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    # standalone P1 / P2 (convolve.h:12-13)
+    def computeSmoothedImage(self, img, sigma):
+        img = np.ascontiguousarray(img, np.float32)
+        out = np.empty_like(img)
+        _check(lib().gklt_smooth(self.h, _fp(img), img.shape[1], img.shape[0], C.c_float(sigma), _fp(out)))
+        return out
+
+    def computeGradients(self, img, sigma):
+        img = np.ascontiguousarray(img, np.float32)
+        gx, gy = np.empty_like(img), np.empty_like(img)
+        _check(lib().gklt_gradients(self.h, _fp(img), img.shape[1], img.shape[0], C.c_float(sigma), _fp(gx), _fp(gy)))
+        return gx, gy
+
+
+class Pyramid:
+    """Device-resident counterpart of the reference's std::vector<cv::Mat> pyramid."""
+
+    def __init__(self, ctx, W, H):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.W, self.H = W, H
+        _check(lib().gklt_pyramid_create(ctx.h, W, H, C.byref(self.h)))
+
+    @property
+    def nlevels(self):
+        return lib().gklt_pyramid_levels(self.h)
+
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _check(lib().gklt_pyramid_level_size(self.h, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def build(self, img):
+        """computePyramid (pyramid.h:11) from a host u8 frame; asynchronous."""
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.H, self.W)
+        self._keep = img
+        _check(lib().gklt_pyramid_build(self.ctx.h, self.h, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.strides[0], 0))
+
+    def build_from_device(self, dptr, stride):
+        _check(lib().gklt_pyramid_build(self.ctx.h, self.h, C.cast(C.c_void_p(dptr), C.POINTER(C.c_uint8)), stride, 1))
+
+    def plane(self, level, plane):
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.float32)
+        _check(lib().gklt_pyramid_download(self.ctx.h, self.h, level, plane, _fp(out), w))
+        return out
+
+    def planes(self):
+        return [self.plane(l, c) for l in range(self.nlevels) for c in range(3)]
+
+    def upload(self, level, plane, arr):
+        arr = np.ascontiguousarray(arr, np.float32)
+        _check(lib().gklt_pyramid_upload(self.ctx.h, self.h, level, plane, _fp(arr), arr.shape[1]))
+
+    def close(self):
+        if self.h:
+            lib().gklt_pyramid_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class FeatureList:
+    """Device-resident SoA feature list (x, y, val of KLT_FeatureRec, KLT.h:76-80)."""
+
+    def __init__(self, ctx, capacity):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        self.capacity = capacity
+        _check(lib().gklt_flist_create(ctx.h, capacity, C.byref(self.h)))
+
+    def upload(self, x, y, val):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        val = np.ascontiguousarray(val, np.int32)
+        _check(lib().gklt_flist_upload(self.ctx.h, self.h, len(x), _fp(x), _fp(y), _ip(val)))
+        self.ctx.sync()
+
+    def __len__(self):
+        return lib().gklt_flist_size(self.h)
+
+    def download(self):
+        n = len(self)
+        x, y, v = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        _check(lib().gklt_flist_download(self.ctx.h, self.h, _fp(x), _fp(y), _ip(v)))
+        return x, y, v
+
+    def download_async(self, x, y, v):
+        _check(lib().gklt_flist_download_async(self.ctx.h, self.h, _fp(x), _fp(y), _ip(v)))
+
+    def stats(self, reset=False):
+        t, i = C.c_uint64(), C.c_uint64()
+        _check(lib().gklt_flist_stats(self.ctx.h, self.h, C.byref(t), C.byref(i), int(reset)))
+        return t.value, i.value
+
+    def close(self):
+        if self.h:
+            lib().gklt_flist_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def KLTTrackFeatures(ctx, pyr1, pyr2, x, y, val, invK=None):
+    """LK.hpp:972 -- returns updated copies (x, y, val[, norm, vec])."""
+    x = np.array(x, np.float32)
+    y = np.array(y, np.float32)
+    val = np.array(val, np.int32)
+    n = len(x)
+    if invK is None:
+        _check(lib().gklt_track(ctx.h, pyr1.h, pyr2.h, n, _fp(x), _fp(y), _ip(val), None, None, None))
+        return x, y, val
+    invK = np.ascontiguousarray(invK, np.float64)
+    norm = np.zeros((n, 3), np.float64)
+    vec = np.zeros((n, 3), np.float64)
+    dp = C.POINTER(C.c_double)
+    _check(lib().gklt_track(ctx.h, pyr1.h, pyr2.h, n, _fp(x), _fp(y), _ip(val),
+                            invK.ctypes.data_as(dp), norm.ctypes.data_as(dp), vec.ctypes.data_as(dp)))
+    return x, y, val, norm, vec
+
+
+def track_flist(ctx, pyr1, pyr2, fl):
+    _check(lib().gklt_track_flist(ctx.h, pyr1.h, pyr2.h, fl.h))

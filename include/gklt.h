@@ -1,0 +1,166 @@
+/*
+ * gklt.h -- C ABI of the MI355X (gfx950) KLT front end that replaces GSLAM's
+ * pyramid.cpp / convolve.cpp / KLTUtil.cpp / LK.hpp / selectGoodFeatures.hpp.
+ *
+ * Plain pointers and sizes only.  Every function returns 0 on success and a negative
+ * GKLT_E* code on failure; gklt_last_error() returns the message of the calling thread's
+ * last failure.  Citations are file:line under /root/reference/GSLAM/.
+ *
+ * Threading: gklt_pyramid_build() and gklt_track*() may be called concurrently from two host
+ * threads on the same context (the reference builds pyramid t+1 on a std::thread while
+ * tracking t-1 -> t, System.cpp:508-518).  They run on two HIP streams of the context and are
+ * ordered against each other per pyramid by events, so a pyramid is never rebuilt while a
+ * tracker launch still reads it and never tracked before its build finished.
+ */
+#ifndef GKLT_H
+#define GKLT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GKLT_MAX_KERNEL_WIDTH 71 /* KLT.h:107 MAX_KERNEL_WIDTH */
+#define GKLT_MAX_LEVELS 12
+
+/* KLT.h:69-74 */
+#define GKLT_TRACKED 0
+#define GKLT_NOT_FOUND -1
+#define GKLT_SMALL_DET -2
+#define GKLT_MAX_ITERATIONS -3
+#define GKLT_OOB -4
+#define GKLT_LARGE_RESIDUE -5
+
+#define GKLT_EINVAL -1   /* bad argument */
+#define GKLT_EHIP -2     /* a HIP runtime call failed */
+#define GKLT_EKERNEL -3  /* the reference would call KLTError (e.g. kernel wider than 71) */
+#define GKLT_ENOMEM -4
+#define GKLT_ECAPACITY -5 /* feature list capacity exceeded */
+
+/* The fields of KLT_TrackingContextRec (KLT.h:18-67) that the hot path reads. */
+typedef struct gklt_params {
+  int mindist;
+  int window_width, window_height;
+  int min_eigenvalue;
+  float min_determinant;
+  float min_displacement;
+  int max_iterations;
+  float max_residue;
+  float grad_sigma;
+  float smooth_sigma_fact;
+  float pyramid_sigma_fact;
+  float step_factor;
+  int nSkippedPixels;
+  int borderx, bordery;
+  int nPyramidLevels;
+  int subsampling;
+} gklt_params;
+
+typedef struct gklt_ctx gklt_ctx;
+typedef struct gklt_pyramid gklt_pyramid;
+typedef struct gklt_flist gklt_flist;
+
+const char *gklt_last_error(void);
+
+/* ---- K1-K4: context parameters and convolution kernels (host only, no GPU needed) ---- */
+
+/* KLTCreateTrackingContext (KLTUtil.cpp:298-342): defaults of KLTUtil.cpp:12-46, then
+ * KLTChangeTCPyramid(tc,15) and KLTUpdateTCBorder(tc). */
+int gklt_default_params(gklt_params *p);
+/* KLTChangeTCPyramid (KLTUtil.cpp:87-134).  *nfixes (may be NULL) = number of window
+ * corrections applied where the reference prints a KLTWarning. */
+int gklt_change_tc_pyramid(gklt_params *p, int search_range, int *nfixes);
+/* KLTUpdateTCBorder (KLTUtil.cpp:225-295). */
+int gklt_update_tc_border(gklt_params *p);
+/* computeKernels (KLTUtil.cpp:136-199).  gauss/deriv hold >= 71 floats.  GKLT_EKERNEL where
+ * the reference calls KLTError. */
+int gklt_compute_kernels(float sigma, float *gauss, int *gauss_width, float *deriv,
+                         int *deriv_width);
+/* _KLTComputeSmoothSigma (KLTUtil.cpp:215-217). */
+float gklt_compute_smooth_sigma(const gklt_params *p);
+/* KLTCountRemainingFeatures (LK.hpp:27-38). */
+int gklt_count_remaining(int n, const int *val);
+
+/* ---- context ---- */
+
+int gklt_ctx_create(int device, gklt_ctx **out);
+int gklt_ctx_destroy(gklt_ctx *ctx);
+/* Copies *p, applies the window warn-and-fix of LK.hpp:982-1013 and validates. */
+int gklt_ctx_set_params(gklt_ctx *ctx, const gklt_params *p);
+int gklt_ctx_get_params(gklt_ctx *ctx, gklt_params *p);
+/* Waits for both streams of the context. */
+int gklt_sync(gklt_ctx *ctx);
+
+/* ---- P1-P4: pyramid (pyramid.cpp:45-84, convolve.cpp:19-56, System.h:30-56) ---- */
+
+/* Device-resident pyramid for W x H frames at the context's current levels/subsampling. */
+int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_pyramid **out);
+int gklt_pyramid_destroy(gklt_pyramid *pyr);
+int gklt_pyramid_levels(const gklt_pyramid *pyr);
+int gklt_pyramid_level_size(const gklt_pyramid *pyr, int level, int *width, int *height);
+/* computePyramid (pyramid.cpp:45): asynchronous on the context's pyramid stream.  img is an
+ * 8-bit grayscale frame with row stride `stride` bytes, in host memory (img_on_device = 0; it
+ * is staged H2D first) or in device memory (img_on_device = 1). */
+int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *pyr, const uint8_t *img, int stride,
+                       int img_on_device);
+/* Copies plane (0 = image, 1 = gradx, 2 = grady) of `level` to host; dst_stride in floats.
+ * This is pyramid[3*level+plane] of the reference's std::vector<cv::Mat>.  Synchronous. */
+int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *pyr, int level, int plane, float *dst,
+                          int dst_stride);
+/* Overwrites one plane from host memory (tests: track on externally produced pyramids). */
+int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *pyr, int level, int plane, const float *src,
+                        int src_stride);
+
+/* computeSmoothedImage (convolve.cpp:46-56) and computeGradients (convolve.cpp:19-42) on dense
+ * host fp32 images; synchronous. */
+int gklt_smooth(gklt_ctx *ctx, const float *src, int width, int height, float sigma, float *dst);
+int gklt_gradients(gklt_ctx *ctx, const float *src, int width, int height, float sigma,
+                   float *gradx, float *grady);
+
+/* ---- T1-T9: tracker (LK.hpp:413-669, 825-1046) ---- */
+
+/* KLTTrackFeatures (LK.hpp:972): host structure-of-arrays feature list, updated in place;
+ * features with val < 0 are left untouched.  invK (row-major 3x3), norm3 and vec3 (n*3 doubles,
+ * written for TRACKED features only) may all be NULL to skip the bearing-vector epilogue
+ * (LK.hpp:1019-1035).  Synchronous: returns when x, y, val hold the results. */
+int gklt_track(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, int n, float *x, float *y,
+               int *val, const double *invK, double *norm3, double *vec3);
+
+/* Device-resident feature list: lets consecutive frames chain without a host round trip. */
+int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out);
+int gklt_flist_destroy(gklt_flist *fl);
+int gklt_flist_upload(gklt_ctx *ctx, gklt_flist *fl, int n, const float *x, const float *y,
+                      const int *val);
+/* Asynchronous on the tracker stream; x/y/val should be pinned for true overlap.  Follow with
+ * gklt_sync() (or gklt_flist_download, which synchronises). */
+int gklt_flist_download_async(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y, int *val);
+int gklt_flist_download(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y, int *val);
+int gklt_flist_size(const gklt_flist *fl);
+/* Same arithmetic as gklt_track on the device-resident list; asynchronous. */
+int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt_flist *fl);
+/* Running totals accumulated by every gklt_track_flist call on this list since creation /
+ * the last reset: features that ended TRACKED, and Newton iterations executed.  Synchronous. */
+int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked, uint64_t *iterations,
+                     int reset);
+
+/* ---- measurement ---- */
+
+enum {
+  GKLT_K_SMOOTH0 = 0, /* u8 -> smoothed level 0 */
+  GKLT_K_DOWN = 1,    /* pre-decimation smooth + 2x decimation (all levels) */
+  GKLT_K_GRAD = 2,    /* gradients + texel packing (all levels) */
+  GKLT_K_TRACK = 3,
+  GKLT_K_MISC = 4,
+  GKLT_K_COUNT = 5
+};
+/* When enabled, every kernel launch is bracketed by HIP events on its own stream. */
+int gklt_profile_enable(gklt_ctx *ctx, int on);
+/* Synchronises, folds finished event pairs into per-kernel totals, returns them. */
+int gklt_profile_get(gklt_ctx *ctx, int kernel_id, double *total_ms, int64_t *launches);
+int gklt_profile_reset(gklt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

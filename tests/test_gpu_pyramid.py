@@ -1,0 +1,139 @@
+"""GPU parity: pyramid / smoothing / gradients through the C ABI vs the CPU oracle.
+
+Bar: the HIP kernels evaluate the oracle's fp32 expression tree operation for operation
+(-ffp-contract=off), so planes are compared BIT FOR BIT (north_star tolerance: 1e-4 relative).
+"""
+import numpy as np
+import pytest
+
+from gslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(H, W, k=0, seed=11):
+    T = synth.base_texture(H, W, seed=seed, margin=64)
+    T = np.pad(T, ((0, 200), (0, 200)), mode="wrap")
+    return synth.render_frame(T, H, W, k, seed=seed)
+
+
+def _assert_bits(a, b, what):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    assert a.shape == b.shape, what
+    bad = a.view(np.uint32) != b.view(np.uint32)
+    assert not bad.any(), "%s: %d/%d elements differ, max abs %g" % (
+        what, bad.sum(), bad.size, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("H,W,window,levels", [
+    (135, 240, 7, 4),      # halves exactly 3 times? 240x135 -> 120x67 (odd): generic resize path
+    (128, 256, 7, 4),      # exact halving at every level
+    (270, 480, 11, 3),
+    (96, 160, 21, 2),      # as-shipped window / levels
+    (37, 53, 5, 2),        # ragged, smaller than a tile
+    (16, 64, 3, 1),        # single level, exactly one tile
+    (200, 333, 9, 3),
+])
+def test_pyramid_bit_exact(klt, ok, gpu_ctx, H, W, window, levels):
+    img = _frame(H, W)
+    gp = klt.make_params(window=window, levels=levels)
+    op = ok.make_params(window=window, levels=levels)
+    assert gp.borderx == op.borderx
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        pyr.build(img)
+        got = pyr.planes()
+    finally:
+        pyr.close()
+    ref = ok.compute_pyramid(op, img)
+    assert len(got) == len(ref) == 3 * levels
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _assert_bits(a, b, "level %d plane %d" % (i // 3, i % 3))
+
+
+def test_pyramid_subsampling4(klt, ok, gpu_ctx):
+    """KLTChangeTCPyramid can pick subsampling 4 or 8 (KLTUtil.cpp:123-128): bilinear resize path."""
+    H, W = 120, 200
+    img = _frame(H, W)
+    gp = klt.make_params(window=7, levels=2, subsampling=4)
+    op = ok.make_params(window=7, levels=2, subsampling=4)
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        pyr.build(img)
+        got = pyr.planes()
+    finally:
+        pyr.close()
+    for a, b in zip(got, ok.compute_pyramid(op, img)):
+        _assert_bits(a, b, "ss4")
+
+
+def test_pyramid_rebuild_same_buffer(klt, ok, gpu_ctx):
+    """A pyramid buffer is reused frame after frame (PyramidBuffer, System.h:30-56)."""
+    H, W = 128, 192
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        for k in range(3):
+            img = _frame(H, W, k)
+            pyr.build(img)
+            for a, b in zip(pyr.planes(), ok.compute_pyramid(op, img)):
+                _assert_bits(a, b, "frame %d" % k)
+    finally:
+        pyr.close()
+
+
+@pytest.mark.parametrize("sigma", [0.7, 1.0, 1.8, 2.1, 4.0])
+def test_smooth_and_gradients_standalone(klt, ok, gpu_ctx, sigma):
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 255, (70, 131)).astype(np.float32)
+    _assert_bits(gpu_ctx.computeSmoothedImage(img, sigma), ok.smooth(img, sigma), "smooth")
+    gx, gy = gpu_ctx.computeGradients(img, sigma)
+    rx, ry = ok.gradients(img, sigma)
+    _assert_bits(gx, rx, "gradx")
+    _assert_bits(gy, ry, "grady")
+
+
+def test_analytic_images(klt, gpu_ctx):
+    """Constant image: smoothing is the identity to rounding and gradients vanish; unit ramp:
+    gx = 1 away from the border (KLTUtil.cpp:191-196 normalises for unit ramp response)."""
+    const = np.full((40, 80), 77.0, np.float32)
+    s = gpu_ctx.computeSmoothedImage(const, 1.8)
+    assert np.abs(s - 77.0).max() < 1e-4
+    gx, gy = gpu_ctx.computeGradients(const, 1.0)
+    assert np.abs(gx).max() < 1e-4 and np.abs(gy).max() < 1e-4
+    ramp = np.tile(np.arange(80, dtype=np.float32), (40, 1))
+    gx, gy = gpu_ctx.computeGradients(ramp, 1.0)
+    assert np.abs(gx[:, 3:-3] - 1.0).max() < 1e-5
+    assert np.abs(gy).max() < 1e-5
+
+
+def test_bad_sigma_is_an_error(klt, gpu_ctx):
+    """computeKernels calls KLTError when the kernel does not fit 71 taps (KLTUtil.cpp:164-167)."""
+    img = np.zeros((16, 16), np.float32)
+    with pytest.raises(klt.GkltError):
+        gpu_ctx.computeSmoothedImage(img, 40.0)
+
+
+def test_full_size_1080p_properties(klt, ok, gpu_ctx):
+    """BASELINE C2 size: full bit-exact check of level 0/1 rows against the oracle on one frame."""
+    H, W = 1080, 1920
+    img = _frame(H, W)
+    gp = klt.make_params(window=7, levels=4)
+    op = ok.make_params(window=7, levels=4)
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        pyr.build(img)
+        got = pyr.planes()
+    finally:
+        pyr.close()
+    ok.set_threads(8)
+    ref = ok.compute_pyramid(op, img)
+    ok.set_threads(1)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        _assert_bits(a, b, "1080p level %d plane %d" % (i // 3, i % 3))

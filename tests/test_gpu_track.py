@@ -1,0 +1,207 @@
+"""GPU parity: KLTTrackFeatures through the C ABI vs the CPU oracle on identical pyramids.
+
+The kernel keeps the reference's AVX lane assignment and summation order (one feature per 8-lane
+slice) and is built -ffp-contract=off, so positions and status flags are compared EXACTLY
+(north_star tolerance: 0.01 px, >= 99.9 % status agreement).
+"""
+import numpy as np
+import pytest
+
+from gslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _stream(H, W, n, seed=21, noise=1.5):
+    T = synth.base_texture(H, W, seed=seed)
+    return [synth.render_frame(T, H, W, k, seed=seed, noise_sigma=noise) for k in range(n)]
+
+
+def _run_pair(klt, ok, ctx, f0, f1, window, levels, x, y, val, border=None, invK=None, **kw):
+    H, W = f0.shape
+    gp = klt.make_params(window=window, levels=levels, border=border, **kw)
+    op = ok.make_params(window=window, levels=levels, border=border, **kw)
+    ctx.set_params(gp)
+    p0, p1 = klt.Pyramid(ctx, W, H), klt.Pyramid(ctx, W, H)
+    try:
+        p0.build(f0)
+        p1.build(f1)
+        got = klt.KLTTrackFeatures(ctx, p0, p1, x, y, val, invK)
+        # the oracle tracks on the planes the GPU produced (pyramid parity is tested separately)
+        ref = ok.track_features(op, p0.planes(), p1.planes(), x, y, val, invK)
+    finally:
+        p0.close()
+        p1.close()
+    return got, ref
+
+
+def _assert_same(got, ref):
+    gx, gy, gv = got[:3]
+    rx, ry, rv = ref[:3]
+    assert (gv == rv).all(), "status differs on %d features: gpu %s ref %s" % (
+        (gv != rv).sum(), gv[gv != rv][:8], rv[gv != rv][:8])
+    assert (gx.view(np.uint32) == rx.view(np.uint32)).all(), np.abs(gx - rx).max()
+    assert (gy.view(np.uint32) == ry.view(np.uint32)).all(), np.abs(gy - ry).max()
+
+
+@pytest.mark.parametrize("window,levels,H,W,n", [
+    (7, 4, 270, 480, 1000),     # C2 shape, reduced frame
+    (11, 3, 270, 480, 700),     # register path 11x11
+    (21, 2, 200, 320, 300),     # as-shipped window: generic LDS path
+    (5, 3, 135, 240, 333),      # generic path, n not a multiple of 8
+    (9, 2, 135, 240, 64),
+])
+def test_track_exact(klt, ok, gpu_ctx, window, levels, H, W, n):
+    f = _stream(H, W, 2)
+    p = ok.make_params(window=window, levels=levels)
+    x, y = synth.lattice_seeds(H, W, n, p.borderx)
+    val = np.zeros(len(x), np.int32)
+    got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[1], window, levels, x, y, val)
+    _assert_same(got, ref)
+    assert (got[2] == 0).mean() > 0.9  # the synthetic pan is well inside the capture range
+
+
+def test_track_rectangular_window_and_even_fix(klt, ok, gpu_ctx):
+    """Even / too-small windows are corrected (LK.hpp:982-1013): 6x2 becomes 7x3."""
+    H, W = 135, 240
+    f = _stream(H, W, 2)
+    x, y = synth.lattice_seeds(H, W, 100, 20)
+    val = np.zeros(len(x), np.int32)
+    gp = klt.make_params(window=7, levels=2, border=20)
+    gp.window_width, gp.window_height = 6, 2
+    op = ok.make_params(window=7, levels=2, border=20)
+    op.window_width, op.window_height = 7, 3
+    gpu_ctx.set_params(gp)
+    q = gpu_ctx.get_params()
+    assert (q.window_width, q.window_height) == (7, 3)
+    p0, p1 = klt.Pyramid(gpu_ctx, W, H), klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(f[0]); p1.build(f[1])
+        got = klt.KLTTrackFeatures(gpu_ctx, p0, p1, x, y, val)
+        ref = ok.track_features(op, p0.planes(), p1.planes(), x, y, val)
+    finally:
+        p0.close(); p1.close()
+    _assert_same(got, ref)
+
+
+def test_track_status_codes(klt, ok, gpu_ctx):
+    """Every status of KLT.h:69-74 the tracker can produce, on crafted inputs."""
+    H, W = 200, 320
+    T = synth.base_texture(H, W, seed=3)
+    f0 = synth.render_frame(T, H, W, 0, seed=3, noise_sigma=0)
+    f1 = synth.render_frame(T, H, W, 1, seed=3, noise_sigma=0)
+    f0 = f0.copy(); f1 = f1.copy()
+    f0[60:120, 40:110] = 90; f1[60:120, 40:110] = 90       # flat patch -> SMALL_DET
+    rng = np.random.default_rng(9)
+    f1[130:190, 200:300] = rng.integers(0, 255, (60, 100))  # unrelated content -> LARGE_RESIDUE / MAX_ITER
+    x = np.array([80, 75.5, 250, 260.25, 3.0, 316.0, 160, 150.5, 100.0, 30.0], np.float32)
+    y = np.array([90, 95.25, 160, 150.5, 100.0, 100.0, 2.0, 197.5, 50.0, 30.0], np.float32)
+    val = np.array([0, 500, 0, 0, 0, 0, 0, 0, -3, 0], np.int32)   # one already-lost feature
+    got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 7, 2, x, y, val, border=8)
+    _assert_same(got, ref)
+    gv = got[2]
+    assert gv[0] == klt.KLT_SMALL_DET and gv[1] == klt.KLT_SMALL_DET
+    assert gv[4] == klt.KLT_OOB and gv[5] == klt.KLT_OOB and gv[6] == klt.KLT_OOB and gv[7] == klt.KLT_OOB
+    assert gv[8] == -3 and got[0][8] == x[8]              # val < 0 is left untouched (LK.hpp:830)
+    assert set(gv[2:4]) <= {klt.KLT_LARGE_RESIDUE, klt.KLT_MAX_ITERATIONS, klt.KLT_SMALL_DET, klt.KLT_OOB}
+    assert gv[9] == klt.KLT_TRACKED
+    lost = (gv < 0) & (np.arange(len(gv)) != 8)
+    assert (got[0][lost] == -1.0).all() and (got[1][lost] == -1.0).all()  # LK.hpp:888-910
+
+
+def test_track_integer_positions_take_copy_path(klt, ok, gpu_ctx):
+    """weights[0]==1.0 -> memcpy rows (LK.hpp:80-85)."""
+    H, W = 135, 240
+    f = _stream(H, W, 2, noise=0)
+    xs, ys = np.meshgrid(np.arange(40, 200, 9), np.arange(40, 100, 7))
+    x = xs.ravel().astype(np.float32); y = ys.ravel().astype(np.float32)
+    val = np.zeros(len(x), np.int32)
+    got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[0], 7, 1, x, y, val, border=10)
+    _assert_same(got, ref)
+    assert (got[2] == 0).all() and (got[0] == x).all() and (got[1] == y).all()
+
+
+def test_track_bearing_vectors(klt, ok, gpu_ctx):
+    H, W = 135, 240
+    f = _stream(H, W, 2)
+    x, y = synth.lattice_seeds(H, W, 200, 20)
+    val = np.zeros(len(x), np.int32)
+    K = np.array([[210.0, 0, 119.5], [0, 205.0, 67.0], [0, 0, 1]])
+    got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[1], 7, 3, x, y, val, border=20, invK=np.linalg.inv(K))
+    _assert_same(got, ref)
+    m = got[2] == 0
+    assert m.sum() > 100
+    np.testing.assert_allclose(got[3][m], ref[3][m], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(got[4][m], ref[4][m], rtol=1e-15, atol=1e-15)
+    assert (got[3][~m] == 0).all()
+
+
+def test_track_empty_and_all_lost(klt, gpu_ctx):
+    H, W = 64, 96
+    f = _stream(H, W, 1)
+    gpu_ctx.set_params(klt.make_params(window=7, levels=2))
+    p0 = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(f[0])
+        x, y, v = klt.KLTTrackFeatures(gpu_ctx, p0, p0, [], [], [])
+        assert len(x) == 0
+        x, y, v = klt.KLTTrackFeatures(gpu_ctx, p0, p0, [5.0, 6.0], [7.0, 8.0], [-1, -4])
+        assert list(v) == [-1, -4] and list(x) == [5.0, 6.0]
+    finally:
+        p0.close()
+
+
+def test_track_sequence_device_list(klt, ok, gpu_ctx):
+    """Chained frames on the device-resident list (pyramid t+1 built while t-1 -> t is tracked,
+    System.cpp:501-518) equal the oracle run frame by frame; stats count TRACKED features."""
+    H, W, nfr, n = 180, 320, 6, 400
+    f = _stream(H, W, nfr)
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    ring = [klt.Pyramid(gpu_ctx, W, H) for _ in range(3)]
+    fl = klt.FeatureList(gpu_ctx, n)
+    try:
+        fl.upload(x, y, val)
+        ring[0].build(f[0])
+        ring[1].build(f[1])
+        for t in range(1, nfr):
+            if t + 1 < nfr:
+                ring[(t + 1) % 3].build(f[t + 1])
+            klt.track_flist(gpu_ctx, ring[(t - 1) % 3], ring[t % 3], fl)
+        gx, gy, gv = fl.download()
+        tracked_total, iters_total = fl.stats()
+    finally:
+        fl.close()
+        for r in ring:
+            r.close()
+    rx, ry, rv = x, y, val
+    total = 0
+    prev = ok.compute_pyramid(op, f[0])
+    for t in range(1, nfr):
+        cur = ok.compute_pyramid(op, f[t])
+        rx, ry, rv = ok.track_features(op, prev, cur, rx, ry, rv)[:3]
+        total += int((rv == 0).sum())
+        prev = cur
+    _assert_same((gx, gy, gv), (rx, ry, rv))
+    assert tracked_total == total and iters_total > 0
+
+
+def test_full_size_c2_frame_pair(klt, ok, gpu_ctx):
+    """BASELINE C2 at full size (1080p, 4000 features, 4 levels, 7x7), one frame pair."""
+    H, W, n = 1080, 1920, 4000
+    T = synth.base_texture(H, W)
+    f0, f1 = synth.render_frame(T, H, W, 0), synth.render_frame(T, H, W, 1)
+    p = ok.make_params(window=7, levels=4)
+    assert p.borderx == 64
+    x, y = synth.lattice_seeds(H, W, n, p.borderx)
+    val = np.zeros(n, np.int32)
+    ok.set_threads(8)
+    try:
+        got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 7, 4, x, y, val)
+    finally:
+        ok.set_threads(1)
+    _assert_same(got, ref)
+    assert (got[2] == 0).mean() > 0.95
