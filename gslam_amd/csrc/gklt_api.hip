@@ -108,6 +108,7 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   c->device = device;
   gklt_default_params(&c->prm);
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
+  GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr2, hipStreamNonBlocking));
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
   GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
   *out = c;
@@ -118,6 +119,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_pyr);
+  (void)hipStreamSynchronize(ctx->s_pyr2);
   (void)hipStreamSynchronize(ctx->s_trk);
   fold_spans(ctx);
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
@@ -127,6 +129,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   (void)hipFree(ctx->d_norm);
   (void)hipFree(ctx->d_vec);
   (void)hipStreamDestroy(ctx->s_pyr);
+  (void)hipStreamDestroy(ctx->s_pyr2);
   (void)hipStreamDestroy(ctx->s_trk);
   delete ctx;
   return 0;
@@ -151,6 +154,7 @@ extern "C" int gklt_sync(gklt_ctx *ctx) {
   if (!ctx) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   GKLT_HIP(hipStreamSynchronize(ctx->s_pyr));
+  GKLT_HIP(hipStreamSynchronize(ctx->s_pyr2));
   GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
   return 0;
 }
@@ -190,6 +194,8 @@ extern "C" int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_py
   }
   GKLT_HIP(hipEventCreateWithFlags(&py->ready, hipEventDisableTiming));
   GKLT_HIP(hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming));
+  GKLT_HIP(hipEventCreateWithFlags(&py->e_img0, hipEventDisableTiming));
+  GKLT_HIP(hipEventCreateWithFlags(&py->e_grad0, hipEventDisableTiming));
   *out = py;
   return 0;
 }
@@ -198,6 +204,7 @@ extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
   if (!py) return 0;
   (void)hipSetDevice(py->ctx->device);
   (void)hipStreamSynchronize(py->ctx->s_pyr);
+  (void)hipStreamSynchronize(py->ctx->s_pyr2);
   (void)hipStreamSynchronize(py->ctx->s_trk);
   for (int l = 0; l < GKLT_MAX_LEVELS; ++l) {
     if (py->lv[l].img) (void)hipFree(py->lv[l].img);
@@ -206,6 +213,8 @@ extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
   if (py->tmp) (void)hipFree(py->tmp);
   if (py->ready) (void)hipEventDestroy(py->ready);
   if (py->consumed) (void)hipEventDestroy(py->consumed);
+  if (py->e_img0) (void)hipEventDestroy(py->e_img0);
+  if (py->e_grad0) (void)hipEventDestroy(py->e_grad0);
   delete py;
   return 0;
 }
@@ -273,6 +282,11 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
 
   // pyramid.cpp:59-61  u8 -> f32 -> smooth
   if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, smooth0, py->lv[0].img)) return rc;
+  // level-0 gradients (the heaviest launch) run on a second stream beside the decimation chain
+  GKLT_HIP(hipEventRecord(py->e_img0, s));
+  GKLT_HIP(hipStreamWaitEvent(ctx->s_pyr2, py->e_img0, 0));
+  if (int rc = launch_gradients_tex(ctx, ctx->s_pyr2, py->lv, 0, 1, gradg, gradd)) return rc;
+  GKLT_HIP(hipEventRecord(py->e_grad0, ctx->s_pyr2));
   for (int l = 1; l < py->nlevels; ++l) {  // pyramid.cpp:62-66
     const Level &a = py->lv[l - 1], &b = py->lv[l];
     if (a.w == 2 * b.w && a.h == 2 * b.h) {
@@ -282,10 +296,10 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
       if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
     }
   }
-  for (int l = 0; l < py->nlevels; ++l) {  // pyramid.cpp:72-83
-    const Level &a = py->lv[l];
-    if (int rc = launch_gradients_tex(ctx, s, a.img, a.w, a.h, gradg, gradd, a.tex)) return rc;
-  }
+  // pyramid.cpp:72-83: gradients of levels 1.. in one launch
+  if (py->nlevels > 1)
+    if (int rc = launch_gradients_tex(ctx, s, py->lv, 1, py->nlevels - 1, gradg, gradd)) return rc;
+  GKLT_HIP(hipStreamWaitEvent(s, py->e_grad0, 0));
   GKLT_HIP(hipEventRecord(py->ready, s));
   py->has_ready = true;
   return 0;
@@ -391,14 +405,15 @@ extern "C" int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out) 
   gklt_flist *fl = new gklt_flist();
   fl->ctx = ctx;
   fl->capacity = capacity;
-  if (hipMalloc(&fl->x, sizeof(float) * capacity) != hipSuccess ||
-      hipMalloc(&fl->y, sizeof(float) * capacity) != hipSuccess ||
-      hipMalloc(&fl->val, sizeof(int) * capacity) != hipSuccess ||
+  // one allocation [x | y | val], each `capacity` long, so a frame's results leave in one copy
+  if (hipMalloc(&fl->x, 3 * sizeof(float) * (size_t)capacity) != hipSuccess ||
       hipMalloc(&fl->stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     set_error("hipMalloc of a %d-feature list failed", capacity);
     gklt_flist_destroy(fl);
     return GKLT_ENOMEM;
   }
+  fl->y = fl->x + capacity;
+  fl->val = reinterpret_cast<int *>(fl->x + 2 * (size_t)capacity);
   GKLT_HIP(hipMemsetAsync(fl->stats, 0, 2 * sizeof(unsigned long long), ctx->s_trk));
   *out = fl;
   return 0;
@@ -409,8 +424,6 @@ extern "C" int gklt_flist_destroy(gklt_flist *fl) {
   (void)hipSetDevice(fl->ctx->device);
   (void)hipStreamSynchronize(fl->ctx->s_trk);
   (void)hipFree(fl->x);
-  (void)hipFree(fl->y);
-  (void)hipFree(fl->val);
   (void)hipFree(fl->stats);
   delete fl;
   return 0;
@@ -446,6 +459,14 @@ extern "C" int gklt_flist_download_async(gklt_ctx *ctx, gklt_flist *fl, float *x
   if (x) GKLT_HIP(hipMemcpyAsync(x, fl->x, sizeof(float) * n, hipMemcpyDeviceToHost, s));
   if (y) GKLT_HIP(hipMemcpyAsync(y, fl->y, sizeof(float) * n, hipMemcpyDeviceToHost, s));
   if (val) GKLT_HIP(hipMemcpyAsync(val, fl->val, sizeof(int) * n, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+extern "C" int gklt_flist_download_packed_async(gklt_ctx *ctx, gklt_flist *fl, void *dst) {
+  if (!ctx || !fl || !dst) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipMemcpyAsync(dst, fl->x, 3 * sizeof(float) * (size_t)fl->capacity,
+                          hipMemcpyDeviceToHost, ctx->s_trk));
   return 0;
 }
 

@@ -47,6 +47,7 @@ struct gklt_ctx {
   int device = 0;
   gklt_params prm{};
   hipStream_t s_pyr = nullptr;  // pyramid builds
+  hipStream_t s_pyr2 = nullptr; // level-0 gradients, concurrent with the decimation chain
   hipStream_t s_trk = nullptr;  // tracker, feature list copies
   // staging for host frames / host feature lists (grown on demand)
   uint8_t *d_frame = nullptr;
@@ -74,6 +75,8 @@ struct gklt_pyramid {
   gklt::Level lv[GKLT_MAX_LEVELS];
   float *tmp = nullptr;      // level-0-sized scratch plane (generic resize path, plane download)
   hipEvent_t ready = nullptr;     // recorded on s_pyr after a build
+  hipEvent_t e_img0 = nullptr;    // level-0 image smoothed (s_pyr -> s_pyr2)
+  hipEvent_t e_grad0 = nullptr;   // level-0 texels written (s_pyr2 -> s_pyr)
   hipEvent_t consumed = nullptr;  // recorded on s_trk after a tracker launch that read it
   bool has_ready = false, has_consumed = false;
 };
@@ -110,8 +113,9 @@ int launch_smooth_decimate2(gklt_ctx *ctx, hipStream_t s, const float *src, int 
                             const Taps &g, float *dst, int w2, int h2);
 int launch_resize_linear(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h, float *dst,
                          int w2, int h2);
-int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
-                         const Taps &g, const Taps &d, Texel *tex);
+// gradients + texel packing of levels [first, first+count) in ONE launch
+int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const Level *levels, int first, int count,
+                         const Taps &g, const Taps &d);
 int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
                             const Taps &g, const Taps &d, float *gx, float *gy);
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);

@@ -1,6 +1,6 @@
 // Pyramid kernels for gfx950: separable Gaussian smoothing, smoothing + 2x decimation, and
-// Gaussian-derivative gradients, each as ONE launch per level that stages a haloed tile in LDS,
-// runs the row pass LDS -> LDS and the column pass LDS -> HBM.
+// Gaussian-derivative gradients.  Each launch stages a haloed tile in LDS, runs the row pass
+// LDS -> LDS and the column pass LDS -> HBM.
 //
 // Replaces cv::sepFilter2D / cv::resize as called from pyramid.cpp:45-84 and convolve.cpp:19-56.
 // Arithmetic is fp32 with every product and sum rounded separately (the translation unit is
@@ -9,6 +9,12 @@
 //     antisymmetric taps        sum_{j=1..r} kj*(s[+j] - s[-j])
 // with BORDER_REFLECT_101 on the source index, which is the order the test oracle uses, so the
 // planes can be compared bit for bit.
+//
+// Tile = 64 x 16 outputs per 256-thread block: a wavefront owns whole tile rows (lane = column),
+// so LDS rows are read and written conflict-free and HBM rows are 256-byte (fp32) or 1 KiB
+// (texel) contiguous stores.  Kernel radii are template parameters for the radii the reference's
+// sigmas produce (taps live in SGPRs, loops fully unrolled); other radii take the R = 0
+// instantiation, which keeps the taps in LDS.
 //
 // HBM layout written here: per level a planar fp32 image `img` (input of the
 // next level, downloads) and an interleaved texel array (I, gx, gy, 0) that the tracker gathers
@@ -19,9 +25,10 @@ namespace gklt {
 
 namespace {
 
-constexpr int TW = 64;  // output tile width  (one wavefront spans a tile row)
-constexpr int TH = 16;  // output tile height
-constexpr int NT = 256; // threads per block
+constexpr int TW = 64;   // output tile width  (one wavefront spans a tile row)
+constexpr int TH = 16;   // output tile height
+constexpr int NT = 256;  // threads per block
+constexpr int NW = NT / 64;
 
 __device__ __forceinline__ int reflect101(int i, int n) {
   if (n == 1) return 0;
@@ -29,112 +36,174 @@ __device__ __forceinline__ int reflect101(int i, int n) {
   return i;
 }
 
+// Tap storage: compile-time radius -> registers/SGPRs, run-time radius -> LDS copy.
+template <int R>
+struct TapRef {
+  const Taps &t;
+  __device__ __forceinline__ int radius() const { return R; }
+  __device__ __forceinline__ float k(int j) const { return t.k[j]; }
+};
+template <>
+struct TapRef<0> {
+  const float *lds;
+  int r;
+  __device__ __forceinline__ int radius() const { return r; }
+  __device__ __forceinline__ float k(int j) const { return lds[j]; }
+};
+
 // 1-D correlation centred on s[0]; `st` is the element stride between neighbouring samples.
-__device__ __forceinline__ float corr(const float *s, int st, const Taps &t) {
+template <int R, int SYM>
+__device__ __forceinline__ float corr(const float *s, int st, const TapRef<R> &t) {
   float acc;
-  if (t.sym > 0) {
-    acc = t.k[0] * s[0];
-    for (int j = 1; j <= t.r; ++j) acc = acc + t.k[j] * (s[j * st] + s[-j * st]);
+  if (SYM > 0) {
+    acc = t.k(0) * s[0];
+    if constexpr (R > 0) {
+#pragma unroll
+      for (int j = 1; j <= R; ++j) acc = acc + t.k(j) * (s[j * st] + s[-j * st]);
+    } else {
+      for (int j = 1; j <= t.radius(); ++j) acc = acc + t.k(j) * (s[j * st] + s[-j * st]);
+    }
   } else {
     acc = 0.0f;
-    for (int j = 1; j <= t.r; ++j) acc = acc + t.k[j] * (s[j * st] - s[-j * st]);
+    if constexpr (R > 0) {
+#pragma unroll
+      for (int j = 1; j <= R; ++j) acc = acc + t.k(j) * (s[j * st] - s[-j * st]);
+    } else {
+      for (int j = 1; j <= t.radius(); ++j) acc = acc + t.k(j) * (s[j * st] - s[-j * st]);
+    }
   }
   return acc;
 }
 
-// Stage the (TH+2ry) x (TW+2rx) source window of the tile at (x0,y0) into LDS, reflecting at
-// the image border.  Rows of consecutive lanes read consecutive source addresses.
+// Stage the (TH+2r) x (TW+2r) source window of the tile at (x0,y0) into LDS, reflecting at the
+// image border.  Wave w takes rows w, w+4, ...; lanes walk the row, so loads are row-contiguous.
 template <typename SrcT>
-__device__ __forceinline__ void stage_tile(const SrcT *src, int stride, int w, int h, int x0,
-                                           int y0, int rx, int ry, float *in, int inW) {
-  const int inH = TH + 2 * ry;
-  for (int i = threadIdx.x; i < inW * inH; i += NT) {
-    const int ty = i / inW, tx = i - ty * inW;
-    const int sy = reflect101(y0 - ry + ty, h), sx = reflect101(x0 - rx + tx, w);
-    in[i] = static_cast<float>(src[(size_t)sy * stride + sx]);
+__device__ __forceinline__ void stage_tile(const SrcT *__restrict__ src, int stride, int w, int h,
+                                           int x0, int y0, int r, float *in, int inW) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int inH = TH + 2 * r;
+  for (int ty = wave; ty < inH; ty += NW) {
+    const int sy = reflect101(y0 - r + ty, h);
+    const SrcT *row = src + (size_t)sy * stride;
+    for (int tx = lane; tx < inW; tx += 64)
+      in[ty * inW + tx] = static_cast<float>(row[reflect101(x0 - r + tx, w)]);
+  }
+}
+
+template <int R>
+__device__ __forceinline__ TapRef<R> make_taps(const Taps &t, float *lds_slot) {
+  if constexpr (R > 0) {
+    return TapRef<R>{t};
+  } else {
+    if ((int)threadIdx.x <= t.r) lds_slot[threadIdx.x] = t.k[threadIdx.x];
+    return TapRef<0>{lds_slot, t.r};
   }
 }
 
 // ---------------------------------------------------------------- smooth (P1) --------------
 // MODE 0: dst = smoothed plane.  MODE 1: dst = 2x2 mean of the smoothed plane (w2 x h2).
-template <typename SrcT, int MODE>
+template <typename SrcT, int MODE, int R>
 __global__ __launch_bounds__(NT) void k_smooth(const SrcT *__restrict__ src, int stride, int w,
                                                int h, Taps g, float *__restrict__ dst, int w2,
                                                int h2) {
   extern __shared__ __align__(16) float lds[];
-  const int r = g.r;
+  const int r = R > 0 ? R : g.r;
   const int inW = TW + 2 * r, inH = TH + 2 * r;
-  float *in = lds;             // inH x inW
-  float *row = lds + inW * inH; // inH x TW
+  float *in = lds;                // inH x inW
+  float *row = in + inW * inH;    // inH x TW
+  float *tapmem = row + inH * TW; // kMaxRadius+1 floats (R == 0 only)
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const TapRef<R> tg = make_taps<R>(g, tapmem);
 
-  stage_tile(src, stride, w, h, x0, y0, r, r, in, inW);
+  stage_tile(src, stride, w, h, x0, y0, r, in, inW);
   __syncthreads();
-  for (int i = threadIdx.x; i < inH * TW; i += NT) {
-    const int ty = i / TW, tx = i % TW;
-    row[i] = corr(in + ty * inW + tx + r, 1, g);
-  }
+  for (int ty = wave; ty < inH; ty += NW)
+    row[ty * TW + lane] = corr<R, +1>(in + ty * inW + lane + r, 1, tg);
   __syncthreads();
   if (MODE == 0) {
-    for (int i = threadIdx.x; i < TH * TW; i += NT) {
-      const int ty = i / TW, tx = i % TW;
-      const int x = x0 + tx, y = y0 + ty;
-      const float v = corr(row + (ty + r) * TW + tx, TW, g);
+    const int x = x0 + lane;
+#pragma unroll
+    for (int ty = wave; ty < TH; ty += NW) {
+      const int y = y0 + ty;
+      const float v = corr<R, +1>(row + (ty + r) * TW + lane, TW, tg);
       if (x < w && y < h) dst[(size_t)y * w + x] = v;
     }
   } else {
     // smoothed tile back into `in` (free after the row pass), then the 2x2 means
     float *sm = in;
-    for (int i = threadIdx.x; i < TH * TW; i += NT) {
-      const int ty = i / TW, tx = i % TW;
-      sm[i] = corr(row + (ty + r) * TW + tx, TW, g);
-    }
+#pragma unroll
+    for (int ty = wave; ty < TH; ty += NW)
+      sm[ty * TW + lane] = corr<R, +1>(row + (ty + r) * TW + lane, TW, tg);
     __syncthreads();
-    for (int i = threadIdx.x; i < (TH / 2) * (TW / 2); i += NT) {
-      const int ty = i / (TW / 2), tx = i % (TW / 2);
-      const int x = x0 / 2 + tx, y = y0 / 2 + ty;
-      const float *p = sm + (2 * ty) * TW + 2 * tx;
-      const float v = (((p[0] + p[1]) + p[TW]) + p[TW + 1]) * 0.25f;
-      if (x < w2 && y < h2) dst[(size_t)y * w2 + x] = v;
-    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 outputs, one per thread
+    const int x = x0 / 2 + tx, y = y0 / 2 + ty;
+    const float *p = sm + (2 * ty) * TW + 2 * tx;
+    const float v = (((p[0] + p[1]) + p[TW]) + p[TW + 1]) * 0.25f;
+    if (x < w2 && y < h2) dst[(size_t)y * w2 + x] = v;
   }
 }
 
 // ---------------------------------------------------------------- gradients (P2) -----------
 // gx = rows G', cols G ; gy = rows G, cols G'  (convolve.cpp:36-37, pyramid.cpp:77-78).
-// One read of I produces both.  TEX: write (I,gx,gy,0) texels, else two planar outputs.
-template <bool TEX>
-__global__ __launch_bounds__(NT) void k_grad(const float *__restrict__ src, int w, int h, Taps g,
-                                             Taps d, Texel *__restrict__ tex,
-                                             float *__restrict__ gxo, float *__restrict__ gyo) {
-  extern __shared__ __align__(16) float lds[];
-  const int rx = max(g.r, d.r), ry = rx;
-  const int inW = TW + 2 * rx, inH = TH + 2 * ry;
-  float *in = lds;                 // inH x inW
-  float *rowd = in + inW * inH;    // inH x TW : rows filtered with G'
-  float *rowg = rowd + inH * TW;   // inH x TW : rows filtered with G
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+// One read of I produces both.  Several levels can share one launch: block -> level by tile id.
+struct GradJob {
+  const float *src;
+  Texel *tex;
+  float *gx, *gy;  // planar outputs (tex == nullptr)
+  int w, h;
+  int tiles_x;
+  int first_tile;  // prefix sum of tiles over the jobs of the launch
+};
+struct GradBatch {
+  int n;
+  GradJob job[GKLT_MAX_LEVELS];
+};
 
-  stage_tile(src, w, w, h, x0, y0, rx, ry, in, inW);
+// RG / RD: radii of G and G' (0,0 = run time)
+template <int RG, int RD>
+__global__ __launch_bounds__(NT) void k_grad(GradBatch batch, Taps g, Taps d) {
+  extern __shared__ __align__(16) float lds[];
+  constexpr bool kStatic = RG > 0;
+  const int r = kStatic ? (RG > RD ? RG : RD) : max(g.r, d.r);
+  const int inW = TW + 2 * r, inH = TH + 2 * r;
+  float *in = lds;                // inH x inW
+  float *rowd = in + inW * inH;   // inH x TW : rows filtered with G'
+  float *rowg = rowd + inH * TW;  // inH x TW : rows filtered with G
+  float *tapmem = rowg + inH * TW;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  int ji = 0;
+  for (int i = 1; i < batch.n; ++i)
+    if ((int)blockIdx.x >= batch.job[i].first_tile) ji = i;
+  const GradJob J = batch.job[ji];
+  const int tile = blockIdx.x - J.first_tile;
+  const int x0 = (tile % J.tiles_x) * TW, y0 = (tile / J.tiles_x) * TH;
+  const int w = J.w, h = J.h;
+
+  const TapRef<RG> tg = make_taps<RG>(g, tapmem);
+  const TapRef<RD> td = make_taps<RD>(d, tapmem + kMaxRadius + 1);
+
+  stage_tile(J.src, w, w, h, x0, y0, r, in, inW);
   __syncthreads();
-  for (int i = threadIdx.x; i < inH * TW; i += NT) {
-    const int ty = i / TW, tx = i % TW;
-    const float *c = in + ty * inW + tx + rx;
-    rowd[i] = corr(c, 1, d);
-    rowg[i] = corr(c, 1, g);
+  for (int ty = wave; ty < inH; ty += NW) {
+    const float *c = in + ty * inW + lane + r;
+    rowd[ty * TW + lane] = corr<RD, -1>(c, 1, td);
+    rowg[ty * TW + lane] = corr<RG, +1>(c, 1, tg);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TH * TW; i += NT) {
-    const int ty = i / TW, tx = i % TW;
-    const int x = x0 + tx, y = y0 + ty;
-    const float gx = corr(rowd + (ty + ry) * TW + tx, TW, g);
-    const float gy = corr(rowg + (ty + ry) * TW + tx, TW, d);
+  const int x = x0 + lane;
+#pragma unroll
+  for (int ty = wave; ty < TH; ty += NW) {
+    const int y = y0 + ty;
+    const float gx = corr<RG, +1>(rowd + (ty + r) * TW + lane, TW, tg);
+    const float gy = corr<RD, -1>(rowg + (ty + r) * TW + lane, TW, td);
     if (x < w && y < h) {
-      if (TEX) {
-        tex[(size_t)y * w + x] = make_float4(in[(ty + ry) * inW + tx + rx], gx, gy, 0.0f);
+      if (J.tex) {
+        J.tex[(size_t)y * w + x] = make_float4(in[(ty + r) * inW + lane + r], gx, gy, 0.0f);
       } else {
-        gxo[(size_t)y * w + x] = gx;
-        gyo[(size_t)y * w + x] = gy;
+        J.gx[(size_t)y * w + x] = gx;
+        J.gy[(size_t)y * w + x] = gy;
       }
     }
   }
@@ -186,21 +255,76 @@ __global__ void k_tex_insert(Texel *__restrict__ tex, int n, int comp,
 
 inline dim3 tile_grid(int w, int h) { return dim3((w + TW - 1) / TW, (h + TH - 1) / TH); }
 inline size_t smooth_lds(int r) {
-  return sizeof(float) * ((size_t)(TW + 2 * r) * (TH + 2 * r) + (size_t)(TH + 2 * r) * TW);
+  return sizeof(float) * ((size_t)(TW + 2 * r) * (TH + 2 * r) + (size_t)(TH + 2 * r) * TW +
+                          (kMaxRadius + 1));
 }
 inline size_t grad_lds(int r) {
-  return sizeof(float) * ((size_t)(TW + 2 * r) * (TH + 2 * r) + 2 * (size_t)(TH + 2 * r) * TW);
+  return sizeof(float) * ((size_t)(TW + 2 * r) * (TH + 2 * r) + 2 * (size_t)(TH + 2 * r) * TW +
+                          2 * (kMaxRadius + 1));
 }
 
-template <typename K>
-int allow_lds(K kernel, size_t bytes) {
+int allow_lds(const void *kernel, size_t bytes) {
   if (bytes > 160 * 1024) {
     set_error("filter radius needs %zu bytes of LDS (> 160 KiB)", bytes);
     return GKLT_EINVAL;
   }
   if (bytes > 48 * 1024)
-    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    GKLT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return 0;
+}
+
+template <typename SrcT, int MODE>
+int launch_smooth_any(gklt_ctx *ctx, hipStream_t s, int prof_id, const SrcT *src, int stride,
+                      int w, int h, const Taps &g, float *dst, int w2, int h2) {
+  const size_t lds = smooth_lds(g.r);
+  const dim3 grid = tile_grid(w, h), block(NT);
+#define GKLT_SMOOTH_CASE(RR)                                                                  \
+  case RR: {                                                                                  \
+    auto kern = k_smooth<SrcT, MODE, RR>;                                                     \
+    if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;             \
+    ProfScope ps(ctx, s, prof_id);                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, src, stride, w, h, g, dst, w2, h2);         \
+  } break;
+  switch (g.r <= 6 ? g.r : 0) {
+    GKLT_SMOOTH_CASE(1)
+    GKLT_SMOOTH_CASE(2)
+    GKLT_SMOOTH_CASE(3)
+    GKLT_SMOOTH_CASE(4)
+    GKLT_SMOOTH_CASE(5)
+    GKLT_SMOOTH_CASE(6)
+    default: {
+      auto kern = k_smooth<SrcT, MODE, 0>;
+      if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+      ProfScope ps(ctx, s, prof_id);
+      hipLaunchKernelGGL(kern, grid, block, lds, s, src, stride, w, h, g, dst, w2, h2);
+    }
+  }
+#undef GKLT_SMOOTH_CASE
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_grad_batch(gklt_ctx *ctx, hipStream_t s, GradBatch &b, const Taps &g, const Taps &d) {
+  int tiles = 0;
+  for (int i = 0; i < b.n; ++i) {
+    GradJob &J = b.job[i];
+    J.tiles_x = (J.w + TW - 1) / TW;
+    J.first_tile = tiles;
+    tiles += J.tiles_x * ((J.h + TH - 1) / TH);
+  }
+  if (tiles == 0) return 0;
+  const size_t lds = grad_lds(std::max(g.r, d.r));
+  ProfScope ps(ctx, s, GKLT_K_GRAD);
+  if (g.r == 3 && d.r == 3) {  // grad_sigma = 1.0, the only value the reference ever uses
+    auto kern = k_grad<3, 3>;
+    if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, b, g, d);
+  } else {
+    auto kern = k_grad<0, 0>;
+    if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, b, g, d);
+  }
+  GKLT_HIP(hipGetLastError());
   return 0;
 }
 
@@ -208,24 +332,12 @@ int allow_lds(K kernel, size_t bytes) {
 
 int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,
                      const Taps &g, float *dst) {
-  const size_t lds = smooth_lds(g.r);
-  if (int rc = allow_lds(k_smooth<uint8_t, 0>, lds)) return rc;
-  ProfScope ps(ctx, s, GKLT_K_SMOOTH0);
-  hipLaunchKernelGGL((k_smooth<uint8_t, 0>), tile_grid(w, h), dim3(NT), lds, s, src, stride, w, h,
-                     g, dst, 0, 0);
-  GKLT_HIP(hipGetLastError());
-  return 0;
+  return launch_smooth_any<uint8_t, 0>(ctx, s, GKLT_K_SMOOTH0, src, stride, w, h, g, dst, 0, 0);
 }
 
 int launch_smooth_f32(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h, const Taps &g,
                       float *dst, int prof_id) {
-  const size_t lds = smooth_lds(g.r);
-  if (int rc = allow_lds(k_smooth<float, 0>, lds)) return rc;
-  ProfScope ps(ctx, s, prof_id);
-  hipLaunchKernelGGL((k_smooth<float, 0>), tile_grid(w, h), dim3(NT), lds, s, src, w, w, h, g, dst,
-                     0, 0);
-  GKLT_HIP(hipGetLastError());
-  return 0;
+  return launch_smooth_any<float, 0>(ctx, s, prof_id, src, w, w, h, g, dst, 0, 0);
 }
 
 int launch_smooth_decimate2(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
@@ -234,13 +346,7 @@ int launch_smooth_decimate2(gklt_ctx *ctx, hipStream_t s, const float *src, int 
     set_error("smooth_decimate2 needs an exact 2x size ratio");
     return GKLT_EINVAL;
   }
-  const size_t lds = smooth_lds(g.r);
-  if (int rc = allow_lds(k_smooth<float, 1>, lds)) return rc;
-  ProfScope ps(ctx, s, GKLT_K_DOWN);
-  hipLaunchKernelGGL((k_smooth<float, 1>), tile_grid(w, h), dim3(NT), lds, s, src, w, w, h, g, dst,
-                     w2, h2);
-  GKLT_HIP(hipGetLastError());
-  return 0;
+  return launch_smooth_any<float, 1>(ctx, s, GKLT_K_DOWN, src, w, w, h, g, dst, w2, h2);
 }
 
 int launch_resize_linear(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h, float *dst,
@@ -252,26 +358,21 @@ int launch_resize_linear(gklt_ctx *ctx, hipStream_t s, const float *src, int w, 
   return 0;
 }
 
-int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
-                         const Taps &g, const Taps &d, Texel *tex) {
-  const size_t lds = grad_lds(std::max(g.r, d.r));
-  if (int rc = allow_lds(k_grad<true>, lds)) return rc;
-  ProfScope ps(ctx, s, GKLT_K_GRAD);
-  hipLaunchKernelGGL((k_grad<true>), tile_grid(w, h), dim3(NT), lds, s, src, w, h, g, d, tex,
-                     (float *)nullptr, (float *)nullptr);
-  GKLT_HIP(hipGetLastError());
-  return 0;
+int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const Level *levels, int first, int count,
+                         const Taps &g, const Taps &d) {
+  GradBatch b{};
+  for (int i = 0; i < count; ++i) {
+    const Level &L = levels[first + i];
+    b.job[b.n++] = GradJob{L.img, L.tex, nullptr, nullptr, L.w, L.h, 0, 0};
+  }
+  return launch_grad_batch(ctx, s, b, g, d);
 }
 
 int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
                             const Taps &g, const Taps &d, float *gx, float *gy) {
-  const size_t lds = grad_lds(std::max(g.r, d.r));
-  if (int rc = allow_lds(k_grad<false>, lds)) return rc;
-  ProfScope ps(ctx, s, GKLT_K_GRAD);
-  hipLaunchKernelGGL((k_grad<false>), tile_grid(w, h), dim3(NT), lds, s, src, w, h, g, d,
-                     (Texel *)nullptr, gx, gy);
-  GKLT_HIP(hipGetLastError());
-  return 0;
+  GradBatch b{};
+  b.job[b.n++] = GradJob{src, nullptr, gx, gy, w, h, 0, 0};
+  return launch_grad_batch(ctx, s, b, g, d);
 }
 
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp,

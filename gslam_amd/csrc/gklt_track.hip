@@ -54,14 +54,17 @@ __device__ __forceinline__ Bilin bilinear_weight(float x, float y) {
   b.w1 = (float)((ax) * (1.0 - ay));
   b.w2 = (float)((1.0 - ax) * ay);
   b.w3 = ax * ay;
+  // Integer position: the reference copies rows instead of interpolating (LK.hpp:80-85).  With
+  // the other three weights forced to zero the interpolation formula returns the same sample
+  // ((p00*1 + p01*0) + (p10*0 + p11*0) == p00 for finite texels) and stays branch-free, so all
+  // gathers of a pass can be in flight together.
+  if (b.w0 == 1.0f) { b.w1 = 0.f; b.w2 = 0.f; b.w3 = 0.f; }
   return b;
 }
 
 // One window element of computeBilinearPatch (LK.hpp:71-108) for all three planes at once.
-__device__ __forceinline__ float3 sample(const Texel *__restrict__ base, int nc, const Bilin &b,
-                                         bool copy_path) {
+__device__ __forceinline__ float3 sample(const Texel *__restrict__ base, int nc, const Bilin &b) {
   const Texel t00 = base[0], t01 = base[1], t10 = base[nc], t11 = base[nc + 1];
-  if (copy_path) return make_float3(t00.x, t00.y, t00.z);  // LK.hpp:80-85 memcpy rows
   float3 o;
   o.x = (t00.x * b.w0 + t01.x * b.w1) + (t10.x * b.w2 + t11.x * b.w3);
   o.y = (t00.y * b.w0 + t01.y * b.w1) + (t10.y * b.w2 + t11.y * b.w3);
@@ -69,10 +72,8 @@ __device__ __forceinline__ float3 sample(const Texel *__restrict__ base, int nc,
   return o;
 }
 
-__device__ __forceinline__ float sample_i(const Texel *__restrict__ base, int nc, const Bilin &b,
-                                          bool copy_path) {
+__device__ __forceinline__ float sample_i(const Texel *__restrict__ base, int nc, const Bilin &b) {
   const float p00 = base[0].x, p01 = base[1].x, p10 = base[nc].x, p11 = base[nc + 1].x;
-  if (copy_path) return p00;
   return (p00 * b.w0 + p01 * b.w1) + (p10 * b.w2 + p11 * b.w3);
 }
 
@@ -99,6 +100,14 @@ __device__ __forceinline__ void clamp_origin(Bilin &b, int hw, int hh, int nc, i
   b.yt = min(max(b.yt, hh), nr - 2 - hh);
 }
 
+// Window element i of the slice lane, clamped so that the (zero-valued) tail elements of the
+// padded patch (alignedPatchSize, LK.hpp:448) still form a valid address: loads stay
+// unconditional, which lets the compiler keep a whole pass of gathers in flight.
+__device__ __forceinline__ int elem_offset(int i, int npix, int ww, int nc) {
+  const int ic = min(i, npix - 1);
+  return (ic / ww) * nc + (ic % ww);
+}
+
 // WW,WH > 0: compile-time window, template patch in registers.
 // WW == 0 : run-time window, template patch in LDS ([plane][element][lane]).
 template <int WW, int WH>
@@ -117,6 +126,7 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 
   extern __shared__ __align__(16) float lds[];  // generic kernel only: 3 * ne * 64 floats
   float P1[NE], GX1[NE], GY1[NE];
+  float3 S2[NE];
 
   const int lane = threadIdx.x;
   const int k = lane & (SL - 1);
@@ -149,21 +159,32 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
       // template patches of frame 1 (:467-476; sampled after the bounds test)
       Bilin b1 = bilinear_weight(x1, y1);
       clamp_origin(b1, hw, hh, nc, nr);
-      const bool copy1 = b1.w0 == 1.0f;
       const Texel *o1 = L.t1 + (size_t)(b1.yt - hh) * nc + (b1.xt - hw);
+      Bilin b2 = bilinear_weight(x2, y2);  // :568-572
+      clamp_origin(b2, hw, hh, nc, nr);
+      const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+
       if constexpr (kStatic) {
+        // template gathers and the first iteration's gathers are issued together
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
           const int i = e * SL + k;
-          float3 s = make_float3(0.f, 0.f, 0.f);
-          if (i < WW * WH) s = sample(o1 + (i / WW) * nc + (i % WW), nc, b1, copy1);
+          float3 s = sample(o1 + elem_offset(i, WW * WH, WW, nc), nc, b1);
+          if (e * SL + SL - 1 >= WW * WH && i >= WW * WH) s = make_float3(0.f, 0.f, 0.f);
           P1[e] = s.x; GX1[e] = s.y; GY1[e] = s.z;
         }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+          const int i = e * SL + k;
+          S2[e] = sample(o2 + elem_offset(i, WW * WH, WW, nc), nc, b2);
+          if (e * SL + SL - 1 >= WW * WH && i >= WW * WH) S2[e] = make_float3(0.f, 0.f, 0.f);
+        }
       } else {
+#pragma unroll 4
         for (int e = 0; e < ne; ++e) {
           const int i = e * SL + k;
-          float3 s = make_float3(0.f, 0.f, 0.f);
-          if (i < npix) s = sample(o1 + (i / ww) * nc + (i % ww), nc, b1, copy1);
+          float3 s = sample(o1 + elem_offset(i, npix, ww, nc), nc, b1);
+          if (i >= npix) s = make_float3(0.f, 0.f, 0.f);
           lds[(0 * ne + e) * 64 + lane] = s.x;
           lds[(1 * ne + e) * 64 + lane] = s.y;
           lds[(2 * ne + e) * 64 + lane] = s.z;
@@ -172,15 +193,8 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 
       float dx, dy;
       for (;;) {
-        Bilin b2 = bilinear_weight(x2, y2);  // :568-572
-        clamp_origin(b2, hw, hh, nc, nr);
-        const bool copy2 = b2.w0 == 1.0f;
-        const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         float axx = 0.f, ayy = 0.f, axy = 0.f, aex = 0.f, aey = 0.f;
-        auto accumulate = [&](int e, float p1, float g1x, float g1y) {
-          const int i = e * SL + k;
-          float3 s = make_float3(0.f, 0.f, 0.f);
-          if (i < npix) s = sample(o2 + (i / ww) * nc + (i % ww), nc, b2, copy2);
+        auto accumulate = [&](float p1, float g1x, float g1y, const float3 &s) {
           const float diff = p1 - s.x;   // computeImageDiff :110-116
           const float gx = g1x + s.y;    // computeImageSum  :118-125
           const float gy = g1y + s.z;
@@ -192,11 +206,16 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
         };
         if constexpr (kStatic) {
 #pragma unroll
-          for (int e = 0; e < NE; ++e) accumulate(e, P1[e], GX1[e], GY1[e]);
+          for (int e = 0; e < NE; ++e) accumulate(P1[e], GX1[e], GY1[e], S2[e]);
         } else {
-          for (int e = 0; e < ne; ++e)
-            accumulate(e, lds[(0 * ne + e) * 64 + lane], lds[(1 * ne + e) * 64 + lane],
-                       lds[(2 * ne + e) * 64 + lane]);
+#pragma unroll 8
+          for (int e = 0; e < ne; ++e) {
+            const int i = e * SL + k;
+            float3 s = sample(o2 + elem_offset(i, npix, ww, nc), nc, b2);
+            if (i >= npix) s = make_float3(0.f, 0.f, 0.f);
+            accumulate(lds[(0 * ne + e) * 64 + lane], lds[(1 * ne + e) * 64 + lane],
+                       lds[(2 * ne + e) * 64 + lane], s);
+          }
         }
         const float gxx = slice_sum(axx), gyy = slice_sum(ayy), gxy = slice_sum(axy);
         const float ex = slice_sum(aex) * a.step_factor, ey = slice_sum(aey) * a.step_factor;
@@ -211,27 +230,47 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
         if (!((fabsf(dx) >= a.min_disp || fabsf(dy) >= a.min_disp) && iteration < a.max_iter))
           break;  // :615
         if (window_oob(x2, y2, hw, hh, nc, nr)) { status = GKLT_OOB; break; }  // next pass :558
+        b2 = bilinear_weight(x2, y2);  // :568-572
+        clamp_origin(b2, hw, hh, nc, nr);
+        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        if constexpr (kStatic) {
+#pragma unroll
+          for (int e = 0; e < NE; ++e) {
+            const int i = e * SL + k;
+            S2[e] = sample(o2 + elem_offset(i, WW * WH, WW, nc), nc, b2);
+            if (e * SL + SL - 1 >= WW * WH && i >= WW * WH) S2[e] = make_float3(0.f, 0.f, 0.f);
+          }
+        }
       }
 
       if (window_oob(x2, y2, hw, hh, nc, nr)) status = GKLT_OOB;  // :620-623
 
-      if (status == GKLT_TRACKED) {  // residue, :626-636
-        Bilin b2 = bilinear_weight(x2, y2);
+      // Residue, :626-636.  At levels above 0 its only effect would be KLT_LARGE_RESIDUE, which
+      // neither stops the descent (:879) nor survives it (the next level overwrites val), so it
+      // is evaluated at level 0 only.
+      if (status == GKLT_TRACKED && r == 0) {
+        b2 = bilinear_weight(x2, y2);
         clamp_origin(b2, hw, hh, nc, nr);
-        const bool copy2 = b2.w0 == 1.0f;
-        const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         float asum = 0.f;
-        auto accumulate = [&](int e, float p1) {
-          const int i = e * SL + k;
-          float s = 0.f;
-          if (i < npix) s = sample_i(o2 + (i / ww) * nc + (i % ww), nc, b2, copy2);
-          asum = asum + fabsf(p1 - s);  // computeABSImageDiff :193-208
-        };
         if constexpr (kStatic) {
+          float sv[NE];
 #pragma unroll
-          for (int e = 0; e < NE; ++e) accumulate(e, P1[e]);
+          for (int e = 0; e < NE; ++e) {
+            const int i = e * SL + k;
+            sv[e] = sample_i(o2 + elem_offset(i, WW * WH, WW, nc), nc, b2);
+            if (e * SL + SL - 1 >= WW * WH && i >= WW * WH) sv[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < NE; ++e) asum = asum + fabsf(P1[e] - sv[e]);  // :193-208
         } else {
-          for (int e = 0; e < ne; ++e) accumulate(e, lds[(0 * ne + e) * 64 + lane]);
+#pragma unroll 8
+          for (int e = 0; e < ne; ++e) {
+            const int i = e * SL + k;
+            float sI = sample_i(o2 + elem_offset(i, npix, ww, nc), nc, b2);
+            if (i >= npix) sI = 0.f;
+            asum = asum + fabsf(lds[(0 * ne + e) * 64 + lane] - sI);
+          }
         }
         if (slice_sum(asum) / (ww * wh) > a.max_residue) status = GKLT_LARGE_RESIDUE;
       }

@@ -263,6 +263,9 @@ class FeatureList:
     def download_async(self, x, y, v):
         _check(lib().gklt_flist_download_async(self.ctx.h, self.h, _fp(x), _fp(y), _ip(v)))
 
+    def download_packed_async(self, dst_ptr):
+        _check(lib().gklt_flist_download_packed_async(self.ctx.h, self.h, C.c_void_p(dst_ptr)))
+
     def stats(self, reset=False):
         t, i = C.c_uint64(), C.c_uint64()
         _check(lib().gklt_flist_stats(self.ctx.h, self.h, C.byref(t), C.byref(i), int(reset)))

@@ -136,6 +136,9 @@ int gklt_flist_upload(gklt_ctx *ctx, gklt_flist *fl, int n, const float *x, cons
  * gklt_sync() (or gklt_flist_download, which synchronises). */
 int gklt_flist_download_async(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y, int *val);
 int gklt_flist_download(gklt_ctx *ctx, gklt_flist *fl, float *x, float *y, int *val);
+/* One asynchronous copy of the whole list: dst (3 * capacity * 4 bytes, ideally pinned) receives
+ * x[capacity] | y[capacity] | val[capacity] back to back. */
+int gklt_flist_download_packed_async(gklt_ctx *ctx, gklt_flist *fl, void *dst);
 int gklt_flist_size(const gklt_flist *fl);
 /* Same arithmetic as gklt_track on the device-resident list; asynchronous. */
 int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt_flist *fl);
