@@ -87,6 +87,7 @@ static int check_params(const gklt_params &p) {
 
 using namespace gklt;
 
+
 // ====================================================================== context
 extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   if (!out) return GKLT_EINVAL;
@@ -108,7 +109,6 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   c->device = device;
   gklt_default_params(&c->prm);
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
-  GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr2, hipStreamNonBlocking));
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
   GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
   *out = c;
@@ -119,7 +119,6 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_pyr);
-  (void)hipStreamSynchronize(ctx->s_pyr2);
   (void)hipStreamSynchronize(ctx->s_trk);
   fold_spans(ctx);
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
@@ -129,7 +128,6 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   (void)hipFree(ctx->d_norm);
   (void)hipFree(ctx->d_vec);
   (void)hipStreamDestroy(ctx->s_pyr);
-  (void)hipStreamDestroy(ctx->s_pyr2);
   (void)hipStreamDestroy(ctx->s_trk);
   delete ctx;
   return 0;
@@ -154,7 +152,6 @@ extern "C" int gklt_sync(gklt_ctx *ctx) {
   if (!ctx) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   GKLT_HIP(hipStreamSynchronize(ctx->s_pyr));
-  GKLT_HIP(hipStreamSynchronize(ctx->s_pyr2));
   GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
   return 0;
 }
@@ -194,8 +191,6 @@ extern "C" int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_py
   }
   GKLT_HIP(hipEventCreateWithFlags(&py->ready, hipEventDisableTiming));
   GKLT_HIP(hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming));
-  GKLT_HIP(hipEventCreateWithFlags(&py->e_img0, hipEventDisableTiming));
-  GKLT_HIP(hipEventCreateWithFlags(&py->e_grad0, hipEventDisableTiming));
   *out = py;
   return 0;
 }
@@ -204,7 +199,6 @@ extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
   if (!py) return 0;
   (void)hipSetDevice(py->ctx->device);
   (void)hipStreamSynchronize(py->ctx->s_pyr);
-  (void)hipStreamSynchronize(py->ctx->s_pyr2);
   (void)hipStreamSynchronize(py->ctx->s_trk);
   for (int l = 0; l < GKLT_MAX_LEVELS; ++l) {
     if (py->lv[l].img) (void)hipFree(py->lv[l].img);
@@ -213,8 +207,6 @@ extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
   if (py->tmp) (void)hipFree(py->tmp);
   if (py->ready) (void)hipEventDestroy(py->ready);
   if (py->consumed) (void)hipEventDestroy(py->consumed);
-  if (py->e_img0) (void)hipEventDestroy(py->e_img0);
-  if (py->e_grad0) (void)hipEventDestroy(py->e_grad0);
   delete py;
   return 0;
 }
@@ -245,21 +237,6 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
   if (int rc = use_device(ctx)) return rc;
   hipStream_t s = ctx->s_pyr;
 
-  // kernels for this call: the reference recomputes them on every call (SURVEY F8)
-  float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
-  int gw, dw;
-  Taps smooth0, pyr, gradg, gradd;
-  if (int rc = gklt_compute_kernels(gklt_compute_smooth_sigma(&P), g, &gw, d, &dw)) return rc;
-  half_taps(g, gw, +1, &smooth0);
-  if (py->nlevels > 1) {
-    if (int rc = gklt_compute_kernels(P.subsampling * P.pyramid_sigma_fact, g, &gw, d, &dw))
-      return rc;  // pyramid.cpp:56
-    half_taps(g, gw, +1, &pyr);
-  }
-  if (int rc = gklt_compute_kernels(P.grad_sigma, g, &gw, d, &dw)) return rc;  // pyramid.cpp:69-71
-  half_taps(g, gw, +1, &gradg);
-  half_taps(d, dw, -1, &gradd);
-
   // do not overwrite planes a tracker launch may still be reading
   if (py->has_consumed) GKLT_HIP(hipStreamWaitEvent(s, py->consumed, 0));
 
@@ -279,14 +256,36 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
     src = ctx->d_frame;
     src_stride = W;
   }
+  if (int rc = enqueue_build(ctx, s, py, src, src_stride)) return rc;
+  GKLT_HIP(hipEventRecord(py->ready, s));
+  py->has_ready = true;
+  return 0;
+}
+
+// The launches of one pyramid build, all on stream s; src is a device u8 frame.  No allocation,
+// no synchronisation, no events (a cross-stream record+wait pair costs ~7 us of host time on this
+// runtime, three kernel launches' worth: tools/hip_overheads.cpp).
+int gklt::enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
+                        int src_stride) {
+  const gklt_params &P = ctx->prm;
+  const int W = py->lv[0].w, H = py->lv[0].h;
+  // kernels for this call: the reference recomputes them on every call (SURVEY F8)
+  float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
+  int gw, dw;
+  Taps smooth0, pyr, gradg, gradd;
+  if (int rc = gklt_compute_kernels(gklt_compute_smooth_sigma(&P), g, &gw, d, &dw)) return rc;
+  half_taps(g, gw, +1, &smooth0);
+  if (py->nlevels > 1) {
+    if (int rc = gklt_compute_kernels(P.subsampling * P.pyramid_sigma_fact, g, &gw, d, &dw))
+      return rc;  // pyramid.cpp:56
+    half_taps(g, gw, +1, &pyr);
+  }
+  if (int rc = gklt_compute_kernels(P.grad_sigma, g, &gw, d, &dw)) return rc;  // pyramid.cpp:69-71
+  half_taps(g, gw, +1, &gradg);
+  half_taps(d, dw, -1, &gradd);
 
   // pyramid.cpp:59-61  u8 -> f32 -> smooth
   if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, smooth0, py->lv[0].img)) return rc;
-  // level-0 gradients (the heaviest launch) run on a second stream beside the decimation chain
-  GKLT_HIP(hipEventRecord(py->e_img0, s));
-  GKLT_HIP(hipStreamWaitEvent(ctx->s_pyr2, py->e_img0, 0));
-  if (int rc = launch_gradients_tex(ctx, ctx->s_pyr2, py->lv, 0, 1, gradg, gradd)) return rc;
-  GKLT_HIP(hipEventRecord(py->e_grad0, ctx->s_pyr2));
   for (int l = 1; l < py->nlevels; ++l) {  // pyramid.cpp:62-66
     const Level &a = py->lv[l - 1], &b = py->lv[l];
     if (a.w == 2 * b.w && a.h == 2 * b.h) {
@@ -296,13 +295,8 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
       if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
     }
   }
-  // pyramid.cpp:72-83: gradients of levels 1.. in one launch
-  if (py->nlevels > 1)
-    if (int rc = launch_gradients_tex(ctx, s, py->lv, 1, py->nlevels - 1, gradg, gradd)) return rc;
-  GKLT_HIP(hipStreamWaitEvent(s, py->e_grad0, 0));
-  GKLT_HIP(hipEventRecord(py->ready, s));
-  py->has_ready = true;
-  return 0;
+  // pyramid.cpp:72-83: gradients of every level in one launch
+  return launch_gradients_tex(ctx, s, py->lv, 0, py->nlevels, gradg, gradd);
 }
 
 extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level, int plane,
@@ -578,5 +572,43 @@ extern "C" int gklt_profile_reset(gklt_ctx *ctx) {
   if (int rc = gklt_sync(ctx)) return rc;
   if (int rc = fold_spans(ctx)) return rc;
   for (int i = 0; i < GKLT_K_COUNT; ++i) { ctx->prof_ms[i] = 0; ctx->prof_n[i] = 0; }
+  return 0;
+}
+
+// ====================================================================== memory helpers
+extern "C" int gklt_device_malloc(gklt_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out || bytes == 0) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipMalloc(out, bytes));
+  return 0;
+}
+extern "C" int gklt_device_free(gklt_ctx *ctx, void *ptr) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipFree(ptr));
+  return 0;
+}
+extern "C" int gklt_host_malloc_pinned(gklt_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out || bytes == 0) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return 0;
+}
+extern "C" int gklt_host_free_pinned(gklt_ctx *ctx, void *ptr) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipHostFree(ptr));
+  return 0;
+}
+extern "C" int gklt_copy_to_device(gklt_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || !dst || !src) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
+  if (!ctx) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipDeviceSynchronize());
   return 0;
 }

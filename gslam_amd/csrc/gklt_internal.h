@@ -47,7 +47,6 @@ struct gklt_ctx {
   int device = 0;
   gklt_params prm{};
   hipStream_t s_pyr = nullptr;  // pyramid builds
-  hipStream_t s_pyr2 = nullptr; // level-0 gradients, concurrent with the decimation chain
   hipStream_t s_trk = nullptr;  // tracker, feature list copies
   // staging for host frames / host feature lists (grown on demand)
   uint8_t *d_frame = nullptr;
@@ -75,8 +74,6 @@ struct gklt_pyramid {
   gklt::Level lv[GKLT_MAX_LEVELS];
   float *tmp = nullptr;      // level-0-sized scratch plane (generic resize path, plane download)
   hipEvent_t ready = nullptr;     // recorded on s_pyr after a build
-  hipEvent_t e_img0 = nullptr;    // level-0 image smoothed (s_pyr -> s_pyr2)
-  hipEvent_t e_grad0 = nullptr;   // level-0 texels written (s_pyr2 -> s_pyr)
   hipEvent_t consumed = nullptr;  // recorded on s_trk after a tracker launch that read it
   bool has_ready = false, has_consumed = false;
 };
@@ -124,6 +121,10 @@ int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp,
 // tracker (gklt_track.hip)
 int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gklt_pyramid *p2,
                  int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
-                 double *d_vec, unsigned long long *stats);
+                 double *d_vec, unsigned long long *stats, float *mirror = nullptr,
+                 int mirror_stride = 0);
+// all launches of one pyramid build on stream s (gklt_api.hip)
+int enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
+                  int src_stride);
 
 }  // namespace gklt

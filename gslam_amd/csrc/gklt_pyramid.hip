@@ -77,16 +77,44 @@ __device__ __forceinline__ float corr(const float *s, int st, const TapRef<R> &t
 
 // Stage the (TH+2r) x (TW+2r) source window of the tile at (x0,y0) into LDS, reflecting at the
 // image border.  Wave w takes rows w, w+4, ...; lanes walk the row, so loads are row-contiguous.
-template <typename SrcT>
+// With a compile-time radius the loops are fully unrolled and every load of the wave is issued
+// before the first LDS store (one HBM round trip per block instead of one per row).
+template <int R, typename SrcT>
 __device__ __forceinline__ void stage_tile(const SrcT *__restrict__ src, int stride, int w, int h,
                                            int x0, int y0, int r, float *in, int inW) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int inH = TH + 2 * r;
-  for (int ty = wave; ty < inH; ty += NW) {
-    const int sy = reflect101(y0 - r + ty, h);
-    const SrcT *row = src + (size_t)sy * stride;
-    for (int tx = lane; tx < inW; tx += 64)
-      in[ty * inW + tx] = static_cast<float>(row[reflect101(x0 - r + tx, w)]);
+  if constexpr (R > 0) {
+    constexpr int IH = TH + 2 * R, IW = TW + 2 * R;
+    constexpr int ROWS = (IH + NW - 1) / NW;
+    static_assert(IW <= 128, "two lane chunks per row");
+    const int sx0 = reflect101(x0 - R + lane, w);
+    const int sx1 = reflect101(x0 - R + 64 + lane, w);
+    SrcT v0[ROWS], v1[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int ty = wave + i * NW;
+      const int sy = reflect101(y0 - R + min(ty, IH - 1), h);
+      const SrcT *row = src + (size_t)sy * stride;
+      v0[i] = row[sx0];
+      v1[i] = row[sx1];
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int ty = wave + i * NW;
+      if (ty < IH) {
+        in[ty * IW + lane] = static_cast<float>(v0[i]);
+        if (lane < IW - 64) in[ty * IW + 64 + lane] = static_cast<float>(v1[i]);
+      }
+    }
+  } else {
+    const int inH = TH + 2 * r;
+#pragma unroll 2
+    for (int ty = wave; ty < inH; ty += NW) {
+      const int sy = reflect101(y0 - r + ty, h);
+      const SrcT *row = src + (size_t)sy * stride;
+      for (int tx = lane; tx < inW; tx += 64)
+        in[ty * inW + tx] = static_cast<float>(row[reflect101(x0 - r + tx, w)]);
+    }
   }
 }
 
@@ -116,7 +144,7 @@ __global__ __launch_bounds__(NT) void k_smooth(const SrcT *__restrict__ src, int
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const TapRef<R> tg = make_taps<R>(g, tapmem);
 
-  stage_tile(src, stride, w, h, x0, y0, r, in, inW);
+  stage_tile<R>(src, stride, w, h, x0, y0, r, in, inW);
   __syncthreads();
   for (int ty = wave; ty < inH; ty += NW)
     row[ty * TW + lane] = corr<R, +1>(in + ty * inW + lane + r, 1, tg);
@@ -184,7 +212,7 @@ __global__ __launch_bounds__(NT) void k_grad(GradBatch batch, Taps g, Taps d) {
   const TapRef<RG> tg = make_taps<RG>(g, tapmem);
   const TapRef<RD> td = make_taps<RD>(d, tapmem + kMaxRadius + 1);
 
-  stage_tile(J.src, w, w, h, x0, y0, r, in, inW);
+  stage_tile<(RG > RD ? RG : RD)>(J.src, w, w, h, x0, y0, r, in, inW);
   __syncthreads();
   for (int ty = wave; ty < inH; ty += NW) {
     const float *c = in + ty * inW + lane + r;

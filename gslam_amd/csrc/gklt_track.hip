@@ -35,6 +35,10 @@ struct TrackArgs {
   int w0, h0, borderx, bordery;
   int n;
   int do_epilogue;
+  // optional host-visible copy of the list: x[stride] | y[stride] | val[stride], written by the
+  // kernel itself (pinned host memory), so no D2H copy sits on the stream after the launch
+  float *mirror;
+  int mirror_stride;
 };
 
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
@@ -297,6 +301,11 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
       fx[f] = tracked ? xo : -1.0f;
       fy[f] = tracked ? yo : -1.0f;
       fval[f] = out;
+      if (a.mirror) {
+        a.mirror[f] = tracked ? xo : -1.0f;
+        a.mirror[a.mirror_stride + f] = tracked ? yo : -1.0f;
+        reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = out;
+      }
       if (tracked && a.do_epilogue) {  // bearing vectors, LK.hpp:1019-1035 (fp64)
         const double px = (double)xo, py = (double)yo;
         double q[3];
@@ -310,6 +319,11 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
         for (int i = 0; i < 3; ++i) vec3[3 * (size_t)f + i] = nv[i] / nv[2];
       }
     }
+  }
+  if (!alive && f < a.n && k == 0 && a.mirror) {  // lost features: mirror the untouched record
+    a.mirror[f] = fx[f];
+    a.mirror[a.mirror_stride + f] = fy[f];
+    reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = fval[f];
   }
   if (stats) {  // one pair of atomics per wave
     const unsigned long long m = __ballot(tracked && k == 0);
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 
 int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gklt_pyramid *p2,
                  int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
-                 double *d_vec, unsigned long long *stats) {
+                 double *d_vec, unsigned long long *stats, float *mirror, int mirror_stride) {
   const gklt_params &P = ctx->prm;
   if (p1->nlevels != P.nPyramidLevels || p2->nlevels != P.nPyramidLevels ||
       p1->ss != P.subsampling || p2->ss != P.subsampling) {
@@ -358,6 +372,8 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
   a.bordery = P.bordery;
   a.n = n;
   a.do_epilogue = d_invk && d_norm && d_vec;
+  a.mirror = mirror;
+  a.mirror_stride = mirror_stride;
   if (n <= 0) return 0;
 
   const dim3 grid((n + 7) / 8), block(64);

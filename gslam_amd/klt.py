@@ -174,6 +174,32 @@ class Context:
             out[name] = (ms.value, n.value)
         return out
 
+    # memory helpers (harness plumbing)
+    def device_upload(self, arr):
+        """Copies a numpy array into a fresh device buffer; returns its address (int)."""
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        _check(lib().gklt_device_malloc(self.h, C.c_size_t(arr.nbytes), C.byref(p)))
+        _check(lib().gklt_copy_to_device(self.h, p, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+        return p.value
+
+    def device_free(self, ptr):
+        _check(lib().gklt_device_free(self.h, C.c_void_p(ptr)))
+
+    def pinned_array(self, shape, dtype):
+        """numpy view of a page-locked host buffer (freed with pinned_free(ptr))."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(lib().gklt_host_malloc_pinned(self.h, C.c_size_t(n), C.byref(p)))
+        buf = (C.c_char * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape), p.value
+
+    def pinned_free(self, ptr):
+        _check(lib().gklt_host_free_pinned(self.h, C.c_void_p(ptr)))
+
+    def device_synchronize(self):
+        _check(lib().gklt_device_synchronize(self.h))
+
     # standalone P1 / P2 (convolve.h:12-13)
     def computeSmoothedImage(self, img, sigma):
         img = np.ascontiguousarray(img, np.float32)
@@ -274,6 +300,77 @@ class FeatureList:
     def close(self):
         if self.h:
             lib().gklt_flist_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class _Borrowed:
+    """A handle owned by another object (no destroy)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, C.c_void_p(h)
+
+
+class Pipeline:
+    """gklt_pipeline: PyramidBuffer (System.h:30-56) + System::Track's per-frame call pattern."""
+
+    def __init__(self, ctx, W, H, capacity):
+        L = lib()
+        L.gklt_pipeline_flist.restype = C.c_void_p
+        L.gklt_pipeline_pyramid.restype = C.c_void_p
+        self.ctx, self.W, self.H, self.capacity = ctx, W, H, capacity
+        self.h = C.c_void_p()
+        _check(L.gklt_pipeline_create(ctx.h, W, H, capacity, C.byref(self.h)))
+        self.flist = FeatureList.__new__(FeatureList)
+        self.flist.ctx, self.flist.capacity = ctx, capacity
+        self.flist.h = C.c_void_p(L.gklt_pipeline_flist(self.h))
+
+    @staticmethod
+    def _img(img):
+        if isinstance(img, np.ndarray):
+            img = np.ascontiguousarray(img, np.uint8)
+            return img, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.strides[0], 0
+        ptr, stride = img  # (device pointer, stride)
+        return None, C.cast(C.c_void_p(ptr), C.POINTER(C.c_uint8)), stride, 1
+
+    def start(self, img0, img1):
+        k0, p0, s0, d0 = self._img(img0)
+        k1, p1, s1, d1 = self._img(img1)
+        assert s0 == s1 and d0 == d1
+        _check(lib().gklt_pipeline_start(self.h, p0, p1, s0, d0))
+        self.sync()
+
+    def step(self, img_next=None, host_out=None):
+        if img_next is None:
+            _check(lib().gklt_pipeline_step(self.h, None, 0, 0, C.c_void_p(host_out)))
+            return
+        keep, p, s, d = self._img(img_next)
+        _check(lib().gklt_pipeline_step(self.h, p, s, d, C.c_void_p(host_out)))
+        if keep is not None:
+            self.sync()  # pageable host frame must stay alive until staged
+
+    def upload_features(self, x, y, val):
+        self._seed = (np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32),
+                      np.ascontiguousarray(val, np.int32))
+        x, y, val = self._seed
+        _check(lib().gklt_pipeline_upload_features(self.h, len(x), _fp(x), _fp(y), _ip(val)))
+
+    def sync(self):
+        _check(lib().gklt_pipeline_sync(self.h))
+
+    def pyramid(self, which):
+        """which = 0 previous, 1 current (after sync)."""
+        py = Pyramid.__new__(Pyramid)
+        py.ctx, py.W, py.H = self.ctx, self.W, self.H
+        py.h = C.c_void_p(lib().gklt_pipeline_pyramid(self.h, which))
+        return py
+
+    def download(self):
+        self.sync()
+        return self.flist.download()
+
+    def close(self):
+        if self.h:
+            lib().gklt_pipeline_destroy(self.h)
             self.h = C.c_void_p()
 
 

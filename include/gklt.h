@@ -147,6 +147,46 @@ int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt
 int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked, uint64_t *iterations,
                      int reset);
 
+/* ---- frame pipeline: PyramidBuffer (System.h:30-56) + the call pattern of System::Track ---- */
+
+/* A 3-deep ring of device pyramids plus a device feature list.  gklt_pipeline_step() does what
+ * one System::Track call does on the front end (System.cpp:501-518): rotate the ring, build the
+ * pyramid of the NEXT frame while tracking previous -> current, and (optionally) deliver the list
+ * to host_out.  Steps are asynchronous on the pipeline's own two streams (which alternate by
+ * frame parity, one event wait per frame); gklt_pipeline_sync() waits for them. */
+typedef struct gklt_pipeline gklt_pipeline;
+int gklt_pipeline_create(gklt_ctx *ctx, int width, int height, int capacity, gklt_pipeline **out);
+int gklt_pipeline_destroy(gklt_pipeline *p);
+/* First frame (System.cpp:367-373): pyramid(img0) becomes "current", pyramid(img1) is preloaded. */
+int gklt_pipeline_start(gklt_pipeline *p, const uint8_t *img0, const uint8_t *img1, int stride,
+                        int img_on_device);
+/* img_next may be NULL for the last frame (track only).  host_out (may be NULL) receives
+ * x[capacity] | y[capacity] | val[capacity]; if it is page-locked (gklt_host_malloc_pinned,
+ * hipHostMalloc) the tracker kernel writes it directly, otherwise a D2H copy is queued.  A host
+ * frame (img_on_device = 0) must stay valid until the step's staging copy has run. */
+int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int stride, int img_on_device,
+                       void *host_out);
+/* Replaces the tracked list (keyframe re-seeding, System.cpp:415-420); ordered with the steps. */
+int gklt_pipeline_upload_features(gklt_pipeline *p, int n, const float *x, const float *y,
+                                  const int *val);
+int gklt_pipeline_sync(gklt_pipeline *p);
+/* The list the pipeline tracks, and its pyramids (which = 0 previous, 1 current) for downloads;
+ * call gklt_pipeline_sync() first. */
+gklt_flist *gklt_pipeline_flist(gklt_pipeline *p);
+gklt_pyramid *gklt_pipeline_pyramid(gklt_pipeline *p, int which);
+
+/* ---- memory helpers for callers that have no HIP of their own (no reference counterpart) ---- */
+
+/* Device buffer on the context's GPU (e.g. decoded frames handed to gklt_pipeline_step with
+ * img_on_device = 1), page-locked host buffer (frame staging, host_out), blocking H2D copy, and
+ * a device-wide synchronise. */
+int gklt_device_malloc(gklt_ctx *ctx, size_t bytes, void **out);
+int gklt_device_free(gklt_ctx *ctx, void *ptr);
+int gklt_host_malloc_pinned(gklt_ctx *ctx, size_t bytes, void **out);
+int gklt_host_free_pinned(gklt_ctx *ctx, void *ptr);
+int gklt_copy_to_device(gklt_ctx *ctx, void *dst, const void *src, size_t bytes);
+int gklt_device_synchronize(gklt_ctx *ctx);
+
 /* ---- measurement ---- */
 
 enum {

@@ -205,3 +205,55 @@ def test_full_size_c2_frame_pair(klt, ok, gpu_ctx):
         ok.set_threads(1)
     _assert_same(got, ref)
     assert (got[2] == 0).mean() > 0.95
+
+
+@pytest.mark.parametrize("pinned_out", [True, False])
+def test_pipeline_matches_oracle(klt, ok, gpu_ctx, pinned_out):
+    """gklt_pipeline (ring rotation, build(t+1) || track(t-1->t) on alternating streams, list
+    delivered into host memory) equals the oracle run frame by frame, including a mid-sequence
+    re-seed and the final track-only step."""
+    H, W, nfr, n = 180, 320, 9, 320
+    f = _stream(H, W, nfr)
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    pipe = klt.Pipeline(gpu_ctx, W, H, n)
+    per_frame = []
+    if pinned_out:
+        out, out_ptr = gpu_ctx.pinned_array((3, n), np.float32)
+    else:
+        out = np.zeros((3, n), np.float32)
+        out_ptr = out.ctypes.data
+    try:
+        pipe.upload_features(x, y, val)
+        pipe.start(f[0], f[1])
+        for t in range(1, nfr):
+            if t == 5:
+                pipe.upload_features(x, y, val)
+            pipe.step(f[t + 1] if t + 1 < nfr else None, out_ptr)
+            per_frame.append(pipe.download())
+            # the host copy written by the step is the same list
+            assert (out[0] == per_frame[-1][0]).all() and (out[1] == per_frame[-1][1]).all()
+            assert (out[2].view(np.int32) == per_frame[-1][2]).all()
+        cur = pipe.pyramid(1).planes()
+        tracked_total, _ = pipe.flist.stats()
+    finally:
+        pipe.close()
+        if pinned_out:
+            gpu_ctx.pinned_free(out_ptr)
+    rx, ry, rv = x, y, val
+    total = 0
+    prev = ok.compute_pyramid(op, f[0])
+    for t in range(1, nfr):
+        if t == 5:
+            rx, ry, rv = x, y, val
+        curp = ok.compute_pyramid(op, f[t])
+        rx, ry, rv = ok.track_features(op, prev, curp, rx, ry, rv)[:3]
+        total += int((rv == 0).sum())
+        _assert_same(per_frame[t - 1], (rx, ry, rv))
+        prev = curp
+    assert tracked_total == total
+    for a, b in zip(cur, prev):   # the "current" pyramid after the last step is frame nfr-1
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
