@@ -237,6 +237,198 @@ __global__ __launch_bounds__(NT) void k_grad(GradBatch batch, Taps g, Taps d) {
   }
 }
 
+// ---------------------------------------------------------------- register-blocked fast path
+// The simple kernels above read LDS once per tap (44 ds_read_b32 per output pair of passes at
+// R = 5) and are LDS-bandwidth bound.  For compile-time radii the passes are register blocked:
+//  * row pass: a thread produces 4 adjacent outputs from one window of NG aligned ds_read_b128
+//    (the halo is padded to a multiple of 4 columns so that every window is 16-byte aligned);
+//  * column pass: a wave owns 4 consecutive rows, a lane one column: 4+2R ds_read_b32 feed a
+//    sliding window that produces 4 outputs.
+// Each output is still the same left-to-right fp32 expression (bit-identical results).
+template <int R>
+struct FastGeom {
+  static constexpr int HP = (R + 3) / 4 * 4;     // halo padded to whole float4 groups
+  static constexpr int IWP = TW + 2 * HP;        // staged row length (multiple of 4)
+  static constexpr int IH = TH + 2 * R;
+  static constexpr int O = HP - R;               // first needed float inside the first group
+  static constexpr int NG = (O + 3 + 2 * R) / 4 + 1;  // float4 groups per 4-output window
+  static constexpr int ROW_TASKS = IH * (TW / 4);
+  static_assert(IWP <= 128 && IWP % 4 == 0, "two lane chunks per staged row");
+};
+
+template <int R, int SYM, int N>
+__device__ __forceinline__ float corr_win(const float (&v)[N], int c, const Taps &t) {
+  float acc;
+  if (SYM > 0) {
+    acc = t.k[0] * v[c];
+#pragma unroll
+    for (int j = 1; j <= R; ++j) acc = acc + t.k[j] * (v[c + j] + v[c - j]);
+  } else {
+    acc = 0.0f;
+#pragma unroll
+    for (int j = 1; j <= R; ++j) acc = acc + t.k[j] * (v[c + j] - v[c - j]);
+  }
+  return acc;
+}
+
+template <int R, typename SrcT>
+__device__ __forceinline__ void stage_fast(const SrcT *__restrict__ src, int stride, int w, int h,
+                                           int x0, int y0, float *in) {
+  using G = FastGeom<R>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int ROWS = (G::IH + NW - 1) / NW;
+  const int sx0 = reflect101(x0 - G::HP + lane, w);
+  const int sx1 = reflect101(x0 - G::HP + 64 + min(lane, G::IWP - 65), w);
+  SrcT v0[ROWS], v1[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int ty = wave + i * NW;
+    const int sy = reflect101(y0 - R + min(ty, G::IH - 1), h);
+    const SrcT *row = src + (size_t)sy * stride;
+    v0[i] = row[sx0];
+    v1[i] = row[sx1];
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int ty = wave + i * NW;
+    if (ty < G::IH) {
+      in[ty * G::IWP + lane] = static_cast<float>(v0[i]);
+      if (lane < G::IWP - 64) in[ty * G::IWP + 64 + lane] = static_cast<float>(v1[i]);
+    }
+  }
+}
+
+// loads the 4-output window of row task (ty, g) into registers
+template <int R>
+__device__ __forceinline__ void load_window(const float *in, int ty, int g,
+                                            float (&v)[4 * FastGeom<R>::NG]) {
+  using G = FastGeom<R>;
+  const float4 *p = reinterpret_cast<const float4 *>(in + ty * G::IWP + 4 * g);
+#pragma unroll
+  for (int q = 0; q < G::NG; ++q) {
+    const float4 f = p[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+}
+
+template <typename SrcT, int MODE, int R>
+__global__ __launch_bounds__(NT) void k_smooth_fast(const SrcT *__restrict__ src, int stride, int w,
+                                                    int h, Taps g, float *__restrict__ dst, int w2,
+                                                    int h2) {
+  using G = FastGeom<R>;
+  extern __shared__ __align__(16) float lds[];
+  float *in = lds;                    // IH x IWP
+  float *row = in + G::IH * G::IWP;   // IH x TW
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  stage_fast<R>(src, stride, w, h, x0, y0, in);
+  __syncthreads();
+#pragma unroll
+  for (int task = threadIdx.x; task < G::ROW_TASKS; task += NT) {
+    const int ty = task >> 4, gq = task & 15;
+    float v[4 * G::NG];
+    load_window<R>(in, ty, gq, v);
+    float4 o;
+    o.x = corr_win<R, +1>(v, G::O + R + 0, g);
+    o.y = corr_win<R, +1>(v, G::O + R + 1, g);
+    o.z = corr_win<R, +1>(v, G::O + R + 2, g);
+    o.w = corr_win<R, +1>(v, G::O + R + 3, g);
+    *reinterpret_cast<float4 *>(row + ty * TW + 4 * gq) = o;
+  }
+  __syncthreads();
+  float v[4 + 2 * R], o[4];
+#pragma unroll
+  for (int i = 0; i < 4 + 2 * R; ++i) v[i] = row[(4 * wave + i) * TW + lane];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = corr_win<R, +1>(v, R + j, g);
+  if (MODE == 0) {
+    const int x = x0 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + 4 * wave + j;
+      if (x < w && y < h) dst[(size_t)y * w + x] = o[j];
+    }
+  } else {
+    // 2x2 mean (((p00 + p01) + p10) + p11) * 0.25: the odd neighbour comes from lane ^ 1
+    const int x = x0 / 2 + (lane >> 1);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const float a = o[2 * jj], c = o[2 * jj + 1];
+      const float b = __shfl_xor(a, 1), d = __shfl_xor(c, 1);
+      const float m = (((a + b) + c) + d) * 0.25f;
+      const int y = y0 / 2 + 2 * wave + jj;
+      if (!(lane & 1) && x < w2 && y < h2) dst[(size_t)y * w2 + x] = m;
+    }
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(NT) void k_grad_fast(GradBatch batch, Taps g, Taps d) {
+  using G = FastGeom<R>;
+  extern __shared__ __align__(16) float lds[];
+  float *in = lds;                      // IH x IWP
+  float *rowd = in + G::IH * G::IWP;    // IH x TW : rows filtered with G'
+  float *rowg = rowd + G::IH * TW;      // IH x TW : rows filtered with G
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  int ji = 0;
+  for (int i = 1; i < batch.n; ++i)
+    if ((int)blockIdx.x >= batch.job[i].first_tile) ji = i;
+  const GradJob J = batch.job[ji];
+  const int tile = blockIdx.x - J.first_tile;
+  const int x0 = (tile % J.tiles_x) * TW, y0 = (tile / J.tiles_x) * TH;
+  const int w = J.w, h = J.h;
+
+  stage_fast<R>(J.src, w, w, h, x0, y0, in);
+  __syncthreads();
+#pragma unroll
+  for (int task = threadIdx.x; task < G::ROW_TASKS; task += NT) {
+    const int ty = task >> 4, gq = task & 15;
+    float v[4 * G::NG];
+    load_window<R>(in, ty, gq, v);
+    float4 od, og;
+    od.x = corr_win<R, -1>(v, G::O + R + 0, d); og.x = corr_win<R, +1>(v, G::O + R + 0, g);
+    od.y = corr_win<R, -1>(v, G::O + R + 1, d); og.y = corr_win<R, +1>(v, G::O + R + 1, g);
+    od.z = corr_win<R, -1>(v, G::O + R + 2, d); og.z = corr_win<R, +1>(v, G::O + R + 2, g);
+    od.w = corr_win<R, -1>(v, G::O + R + 3, d); og.w = corr_win<R, +1>(v, G::O + R + 3, g);
+    *reinterpret_cast<float4 *>(rowd + ty * TW + 4 * gq) = od;
+    *reinterpret_cast<float4 *>(rowg + ty * TW + 4 * gq) = og;
+  }
+  __syncthreads();
+  float vd[4 + 2 * R], vg[4 + 2 * R];
+#pragma unroll
+  for (int i = 0; i < 4 + 2 * R; ++i) {
+    vd[i] = rowd[(4 * wave + i) * TW + lane];
+    vg[i] = rowg[(4 * wave + i) * TW + lane];
+  }
+  const int x = x0 + lane;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int y = y0 + 4 * wave + j;
+    const float gx = corr_win<R, +1>(vd, R + j, g);
+    const float gy = corr_win<R, -1>(vg, R + j, d);
+    if (x < w && y < h) {
+      if (J.tex) {
+        J.tex[(size_t)y * w + x] =
+            make_float4(in[(4 * wave + j + R) * G::IWP + G::HP + lane], gx, gy, 0.0f);
+      } else {
+        J.gx[(size_t)y * w + x] = gx;
+        J.gy[(size_t)y * w + x] = gy;
+      }
+    }
+  }
+}
+
+template <int R>
+constexpr size_t fast_smooth_lds() {
+  return sizeof(float) * (size_t)(FastGeom<R>::IH * FastGeom<R>::IWP + FastGeom<R>::IH * TW);
+}
+template <int R>
+constexpr size_t fast_grad_lds() {
+  return sizeof(float) * (size_t)(FastGeom<R>::IH * FastGeom<R>::IWP + 2 * FastGeom<R>::IH * TW);
+}
+
 // ---------------------------------------------------------------- generic resize -----------
 // cv::resize(INTER_LINEAR) for scales other than exactly 2 (pyramid.cpp:65 with subsampling 4/8
 // or odd sizes): sx = (dx+0.5)*(W/W2)-0.5, source index clamped, horizontal then vertical blend.
@@ -304,14 +496,12 @@ int allow_lds(const void *kernel, size_t bytes) {
 template <typename SrcT, int MODE>
 int launch_smooth_any(gklt_ctx *ctx, hipStream_t s, int prof_id, const SrcT *src, int stride,
                       int w, int h, const Taps &g, float *dst, int w2, int h2) {
-  const size_t lds = smooth_lds(g.r);
   const dim3 grid = tile_grid(w, h), block(NT);
 #define GKLT_SMOOTH_CASE(RR)                                                                  \
   case RR: {                                                                                  \
-    auto kern = k_smooth<SrcT, MODE, RR>;                                                     \
-    if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;             \
     ProfScope ps(ctx, s, prof_id);                                                            \
-    hipLaunchKernelGGL(kern, grid, block, lds, s, src, stride, w, h, g, dst, w2, h2);         \
+    hipLaunchKernelGGL((k_smooth_fast<SrcT, MODE, RR>), grid, block, fast_smooth_lds<RR>(), s, \
+                       src, stride, w, h, g, dst, w2, h2);                                    \
   } break;
   switch (g.r <= 6 ? g.r : 0) {
     GKLT_SMOOTH_CASE(1)
@@ -321,6 +511,7 @@ int launch_smooth_any(gklt_ctx *ctx, hipStream_t s, int prof_id, const SrcT *src
     GKLT_SMOOTH_CASE(5)
     GKLT_SMOOTH_CASE(6)
     default: {
+      const size_t lds = smooth_lds(g.r);
       auto kern = k_smooth<SrcT, MODE, 0>;
       if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
       ProfScope ps(ctx, s, prof_id);
@@ -341,13 +532,13 @@ int launch_grad_batch(gklt_ctx *ctx, hipStream_t s, GradBatch &b, const Taps &g,
     tiles += J.tiles_x * ((J.h + TH - 1) / TH);
   }
   if (tiles == 0) return 0;
-  const size_t lds = grad_lds(std::max(g.r, d.r));
   ProfScope ps(ctx, s, GKLT_K_GRAD);
   if (g.r == 3 && d.r == 3) {  // grad_sigma = 1.0, the only value the reference ever uses
-    auto kern = k_grad<3, 3>;
-    if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, b, g, d);
+    hipLaunchKernelGGL((k_grad_fast<3>), dim3(tiles), dim3(NT), fast_grad_lds<3>(), s, b, g, d);
+  } else if (g.r == 2 && d.r == 2) {
+    hipLaunchKernelGGL((k_grad_fast<2>), dim3(tiles), dim3(NT), fast_grad_lds<2>(), s, b, g, d);
   } else {
+    const size_t lds = grad_lds(std::max(g.r, d.r));
     auto kern = k_grad<0, 0>;
     if (int rc = allow_lds(reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(NT), lds, s, b, g, d);
