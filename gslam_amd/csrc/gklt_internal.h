@@ -43,8 +43,14 @@ struct Level {
 
 }  // namespace gklt
 
+namespace gklt {
+struct SelScratch;  // selector scratch (gklt_select.hip)
+void sel_free(SelScratch *s);
+}  // namespace gklt
+
 struct gklt_ctx {
   int device = 0;
+  gklt::SelScratch *sel = nullptr;
   gklt_params prm{};
   hipStream_t s_pyr = nullptr;  // pyramid builds
   hipStream_t s_trk = nullptr;  // tracker, feature list copies

@@ -394,3 +394,40 @@ def KLTTrackFeatures(ctx, pyr1, pyr2, x, y, val, invK=None):
 
 def track_flist(ctx, pyr1, pyr2, fl):
     _check(lib().gklt_track_flist(ctx.h, pyr1.h, pyr2.h, fl.h))
+
+
+# ---- selector (selectGoodFeatures.hpp) ------------------------------------------------------
+
+SELECT_ALL, REPLACE_SOME = 0, 1
+VARIANT_PLAIN, VARIANT_ROUND2, VARIANT_UNIFORM = 0, 1, 2
+
+
+def integral_products(ctx, pyr):
+    """System.cpp:385-392: integral images of gx*gx, gy*gy, gx*gy of level 0 -> 3 x (H+1, W+1)."""
+    w, h = pyr.level_size(0)
+    s = [np.empty((h + 1, w + 1), np.float32) for _ in range(3)]
+    _check(lib().gklt_integral_products(ctx.h, pyr.h, _fp(s[0]), _fp(s[1]), _fp(s[2])))
+    return s
+
+
+def select_features(ctx, mode, variant, sumxx, sumyy, sumxy, nFeatures, x=None, y=None, val=None,
+                    capacity=None, grid=(20, 20)):
+    """KLTSelectGoodFeatures / KLTReplaceLostFeatures[2|Uniform] on host sums and a host list."""
+    H, W = sumxx.shape[0] - 1, sumxx.shape[1] - 1
+    capacity = capacity or 100 * max(nFeatures, 1)   # KLTCreateFeatureList, KLTUtil.cpp:53-55
+    fx = np.full(capacity, -1, np.float32)
+    fy = np.full(capacity, -1, np.float32)
+    fv = np.full(capacity, -1, np.int32)
+    if x is not None:
+        fx[: len(x)] = x
+        fy[: len(y)] = y
+        fv[: len(val)] = val
+    n = C.c_int(nFeatures)
+    sums = [np.ascontiguousarray(a, np.float32) for a in (sumxx, sumyy, sumxy)]
+    _check(lib().gklt_select(ctx.h, mode, variant, _fp(sums[0]), _fp(sums[1]), _fp(sums[2]), W, H,
+                             C.byref(n), capacity, _fp(fx), _fp(fy), _ip(fv), grid[0], grid[1]))
+    return fx[: n.value].copy(), fy[: n.value].copy(), fv[: n.value].copy()
+
+
+def select_from_pyramid(ctx, pyr, mode, variant, fl):
+    _check(lib().gklt_select_from_pyramid(ctx.h, pyr.h, mode, variant, fl.h))

@@ -37,6 +37,7 @@ extern "C" {
 #define GKLT_EKERNEL -3  /* the reference would call KLTError (e.g. kernel wider than 71) */
 #define GKLT_ENOMEM -4
 #define GKLT_ECAPACITY -5 /* feature list capacity exceeded */
+#define GKLT_EUNSUPPORTED -6 /* a reference entry point that is not built on the GPU yet */
 
 /* The fields of KLT_TrackingContextRec (KLT.h:18-67) that the hot path reads. */
 typedef struct gklt_params {
@@ -147,6 +148,29 @@ int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt
 int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked, uint64_t *iterations,
                      int reset);
 
+/* ---- S1-S6: Shi-Tomasi selection (selectGoodFeatures.hpp, System.cpp:385-392) ---- */
+
+enum { GKLT_SELECT_ALL = 0, GKLT_REPLACE_SOME = 1 };                         /* selectionMode, :34 */
+enum { GKLT_VARIANT_PLAIN = 0, GKLT_VARIANT_ROUND2 = 1, GKLT_VARIANT_UNIFORM = 2 };
+
+/* The inputs the selector presupposes (System.cpp:385-392): gx*gx, gy*gy, gx*gy of pyramid
+ * level 0 and their cv::integral(..., CV_32F) images, each (H+1) x (W+1) dense fp32, to host. */
+int gklt_integral_products(gklt_ctx *ctx, gklt_pyramid *pyr, float *sumDxx, float *sumDyy,
+                           float *sumDxy);
+/* KLTSelectGoodFeatures / KLTReplaceLostFeatures (selectGoodFeatures.hpp:424-449), ...2
+ * (:997-1022) and KLTReplaceLostFeaturesUniform (:1341-1355, which runs the plain replace) on host
+ * integral images and a host SoA list of *nFeatures entries, updated in place.  Ties between
+ * equal scores, unspecified in the reference (qsort), are ordered y ascending then x ascending.
+ * KLTSelectGoodFeaturesUniform (mode ALL, variant UNIFORM) returns GKLT_EUNSUPPORTED for now;
+ * gridW/gridH (the cell size in pixels, selectGoodFeatures.hpp:28) are reserved for it. */
+int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *sumDxx, const float *sumDyy,
+                const float *sumDxy, int width, int height, int *nFeatures, int capacity, float *x,
+                float *y, int *val, int gridW, int gridH);
+/* Same selection with the integral images computed on the device from pyramid level 0 and the
+ * list resident on the device; asynchronous apart from the convergence polls. */
+int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *pyr, int mode, int variant,
+                             gklt_flist *fl);
+
 /* ---- frame pipeline: PyramidBuffer (System.h:30-56) + the call pattern of System::Track ---- */
 
 /* A 3-deep ring of device pyramids plus a device feature list.  gklt_pipeline_step() does what
@@ -195,7 +219,9 @@ enum {
   GKLT_K_GRAD = 2,    /* gradients + texel packing (all levels) */
   GKLT_K_TRACK = 3,
   GKLT_K_MISC = 4,
-  GKLT_K_COUNT = 5
+  GKLT_K_INTEGRAL = 5, /* products + integral images */
+  GKLT_K_SELECT = 6,   /* score, suppression rounds, rank/assign */
+  GKLT_K_COUNT = 7
 };
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream. */
 int gklt_profile_enable(gklt_ctx *ctx, int on);

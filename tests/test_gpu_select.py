@@ -1,0 +1,154 @@
+"""GPU parity: integral images and Shi-Tomasi selection through the C ABI vs the CPU oracle.
+
+Integer / index work: the selected (x, y, val) lists must be IDENTICAL, slot by slot.  The fp32
+integral images are compared bit for bit (same summation order as cv::integral's restatement).
+"""
+import numpy as np
+import pytest
+
+from gslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(H, W, seed=31, k=0):
+    T = synth.base_texture(H, W, seed=seed)
+    return synth.render_frame(T, H, W, k, seed=seed)
+
+
+def _sums(klt, ok, ctx, img, window=7, levels=2):
+    H, W = img.shape
+    ctx.set_params(klt.make_params(window=window, levels=levels))
+    pyr = klt.Pyramid(ctx, W, H)
+    try:
+        pyr.build(img)
+        got = klt.integral_products(ctx, pyr)
+        gx, gy = pyr.plane(0, 1), pyr.plane(0, 2)
+    finally:
+        pyr.close()
+    return got, ok.integral_products(gx, gy)
+
+
+@pytest.mark.parametrize("H,W", [(96, 128), (131, 203), (64, 64), (270, 480)])
+def test_integral_bit_exact(klt, ok, gpu_ctx, H, W):
+    got, ref = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape == (H + 1, W + 1)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), np.abs(a - b).max()
+
+
+def _same_lists(got, ref):
+    for a, b, name in zip(got, ref, "xyv"):
+        assert len(a) == len(b), name
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, "%s differs at %d slots, first %s: gpu %s ref %s" % (
+            name, len(bad), bad[:5], a[bad[:5]], b[bad[:5]])
+
+
+@pytest.mark.parametrize("H,W,n,mindist,min_eig,border,skip", [
+    (135, 240, 200, 10, 100, 12, 0),
+    (135, 240, 5000, 4, 20, 8, 0),      # more slots than the image can hold -> NOT_FOUND tail
+    (270, 480, 600, 10, 200, 32, 0),
+    (96, 128, 50, 1, 50, 4, 0),         # mindist 1: radius 0, every candidate is independent
+    (135, 240, 150, 7, 50, 3, 2),       # nSkippedPixels, border smaller than the window half-width
+    (200, 333, 300, 25, 30, 10, 0),     # large suppression radius, many fixpoint rounds
+])
+def test_select_all_matches_oracle(klt, ok, gpu_ctx, H, W, n, mindist, min_eig, border, skip):
+    _, sums = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    kw = dict(window=7, levels=2, border=border, mindist=mindist, min_eigenvalue=min_eig,
+              nSkippedPixels=skip)
+    gpu_ctx.set_params(klt.make_params(**kw))
+    got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_PLAIN, *sums, n)
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
+    _same_lists(got, ref)
+    assert (got[2] > 0).sum() > 0
+
+
+def test_select_ties_follow_the_documented_order(klt, ok, gpu_ctx):
+    """Equal scores (a periodic pattern) are ordered y ascending, then x ascending."""
+    H, W = 96, 160
+    img = np.zeros((H, W), np.uint8)
+    img[::16, :] = 255
+    img[:, ::16] = 255                                  # identical corners on a 16 px lattice
+    _, sums = _sums(klt, ok, gpu_ctx, img)
+    kw = dict(window=7, levels=2, border=10, mindist=5, min_eigenvalue=10)
+    gpu_ctx.set_params(klt.make_params(**kw))
+    got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_PLAIN, *sums, 400)
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, 400)
+    _same_lists(got, ref)
+    k = (got[2] > 0).sum()
+    assert k > 20 and len(np.unique(got[2][:k])) < k   # there really were ties
+
+
+@pytest.mark.parametrize("variant", ["PLAIN", "ROUND2", "UNIFORM"])
+def test_replace_lost_matches_oracle(klt, ok, gpu_ctx, variant):
+    H, W, n = 135, 240, 160
+    _, sums = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    kw = dict(window=7, levels=2, border=10, mindist=8, min_eigenvalue=60)
+    gp, op = klt.make_params(**kw), ok.make_params(**kw)
+    gpu_ctx.set_params(gp)
+    x, y, v = ok.select_features(op, ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
+    rng = np.random.default_rng(3)
+    lost = rng.choice(n, 60, replace=False)
+    v = np.where(v > 0, 0, v).astype(np.int32)          # survivors look tracked
+    v[lost] = -4; x[lost] = -1; y[lost] = -1
+    x = x + rng.uniform(-0.4, 0.4, n).astype(np.float32) * (v == 0)   # sub-pixel drift
+    gv, ov = getattr(klt, "VARIANT_" + variant), getattr(ok, "VARIANT_" + variant)
+    got = klt.select_features(gpu_ctx, klt.REPLACE_SOME, gv, *sums, n, x, y, v)
+    ref = ok.select_features(op, ok.REPLACE_SOME, ov, *sums, n, x, y, v)
+    _same_lists(got, ref)
+    keep = np.setdiff1d(np.arange(n), lost)
+    assert (got[0][keep] == x[keep]).all() and (got[2][keep] == v[keep]).all()
+    assert (got[2][lost] != -4).all()                   # every lost slot was rewritten
+    # nothing lost: untouched (selectGoodFeatures.hpp:442-447)
+    v2 = np.zeros(n, np.int32)
+    same = klt.select_features(gpu_ctx, klt.REPLACE_SOME, gv, *sums, n, x, y, v2)
+    assert (same[0] == x).all() and (same[2] == 0).all()
+
+
+def test_select_uniform_is_reported_unsupported(klt, gpu_ctx):
+    s = [np.zeros((33, 33), np.float32)] * 3
+    with pytest.raises(klt.GkltError, match="not built on the GPU"):
+        klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *s, 10)
+
+
+def test_select_from_pyramid_device_list(klt, ok, gpu_ctx):
+    """Device-resident path: integrals from level 0, list stays on the GPU, then it is tracked."""
+    H, W, n = 180, 320, 500
+    f0, f1 = _frame(H, W, k=0), _frame(H, W, k=1)
+    kw = dict(window=7, levels=3, mindist=10, min_eigenvalue=100)
+    gp, op = klt.make_params(**kw), ok.make_params(**kw)
+    gpu_ctx.set_params(gp)
+    p0, p1 = klt.Pyramid(gpu_ctx, W, H), klt.Pyramid(gpu_ctx, W, H)
+    fl = klt.FeatureList(gpu_ctx, n)
+    try:
+        p0.build(f0); p1.build(f1)
+        fl.upload(np.full(n, -1, np.float32), np.full(n, -1, np.float32), np.full(n, -1, np.int32))
+        klt.select_from_pyramid(gpu_ctx, p0, klt.SELECT_ALL, klt.VARIANT_PLAIN, fl)
+        sel = fl.download()
+        klt.track_flist(gpu_ctx, p0, p1, fl)
+        trk = fl.download()
+        planes0, planes1 = p0.planes(), p1.planes()
+    finally:
+        fl.close(); p0.close(); p1.close()
+    sums = ok.integral_products(planes0[1], planes0[2])
+    ref = ok.select_features(op, ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
+    _same_lists(sel, ref)
+    rt = ok.track_features(op, planes0, planes1, *ref)[:3]
+    _same_lists(trk, rt)
+    assert (trk[2] == 0).sum() > 0.8 * (ref[2] > 0).sum()
+
+
+def test_full_size_1080p_select(klt, ok, gpu_ctx):
+    """BASELINE C5 size (plain flavour): 1080p, 4000 slots, mindist 10, min_eigenvalue 100."""
+    H, W, n = 1080, 1920, 4000
+    img = _frame(H, W)
+    got_s, sums = _sums(klt, ok, gpu_ctx, img, levels=4)
+    for a, b in zip(got_s, sums):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    kw = dict(window=7, levels=4, mindist=10, min_eigenvalue=100)
+    gpu_ctx.set_params(klt.make_params(**kw))
+    got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_PLAIN, *sums, n)
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
+    _same_lists(got, ref)
+    assert (got[2] > 0).all()                           # a textured 1080p frame fills 4000 slots
