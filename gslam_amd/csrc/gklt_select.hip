@@ -17,6 +17,8 @@
 //      acceptances, i.e. it keeps the nFeatures highest-priority members of that set:
 //      k_rank_assign ranks the accepted set and writes slot[rank].
 #include <algorithm>
+#include <utility>
+#include <vector>
 
 #include "gklt_internal.h"
 
@@ -307,7 +309,10 @@ struct SelScratch {
   unsigned *counters = nullptr;  // [0] accepted count, [1..] per-round undecided
   int *slots = nullptr, *nslots = nullptr;
   unsigned *h_counters = nullptr;  // pinned
+  struct UniScratch *uni = nullptr;  // extra buffers of the Uniform flavour
 };
+struct UniScratch;
+void uni_free(UniScratch *u);
 constexpr int kMaxRounds = 4096;
 constexpr int kRoundBatch = 4;
 
@@ -321,6 +326,7 @@ void sel_free(SelScratch *s) {
   (void)hipFree(s->slots);
   (void)hipFree(s->nslots);
   if (s->h_counters) (void)hipHostFree(s->h_counters);
+  uni_free(s->uni);
   delete s;
 }
 
@@ -459,6 +465,453 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   return 0;
 }
 
+
+// ====================================================================== S5: Uniform selection
+// _KLTSelectGoodFeaturesUniform (selectGoodFeatures.hpp:1064-1316) walks the grid cells centre-out
+// and each cell's candidates in descending score.  While list slots remain it accepts every
+// candidate no accepted feature covers (radius mindist, :1288).  Once the slots are used up
+// (indx >= nFeatures) it keeps going but grows the list by one slot at a time and leaves a cell
+// as soon as that cell holds more than minFeatureInGrid features (:1252-1271).  Which candidates
+// are accepted is therefore a priority-greedy walk with a per-cell cap:
+//   cells before the one where the slots ran out: no cap;
+//   that cell: cap = max(features it held when they ran out, minFeatureInGrid + 1);
+//   later cells: cap = minFeatureInGrid + 1,
+// priority = (cell visiting order, val desc, y asc, x asc).  The same fixpoint as the plain
+// selector computes it, with two extra conditions on ACCEPT in capped cells: the candidate must
+// also be the highest-priority undecided candidate of its own cell (one acceptance per cell and
+// round keeps the count exact) and the cell must still be below its cap; a full cell rejects all
+// its remaining candidates.  Phase A runs uncapped and locates the candidate T that takes the
+// last original slot; everything of lower priority is then re-decided under the caps (phase B).
+// A grown slot that no later candidate fills stays as one trailing KLT_NOT_FOUND entry.
+namespace {
+
+struct UGrid {
+  int gw, gh, cw, ch;
+  const unsigned short *rank;  // visiting rank of each cell (0 = first)
+};
+
+__device__ __forceinline__ int ucell(int x, int y, const UGrid &g) {
+  // the reference indexes past its grid in the remainder strip (W % gw != 0); clamped here
+  return min(y / g.gh, g.ch - 1) * g.cw + min(x / g.gw, g.cw - 1);
+}
+__device__ __forceinline__ unsigned long long ukey(unsigned val, int x, int y, const UGrid &g) {
+  const int cx = min(x / g.gw, g.cw - 1), cy = min(y / g.gh, g.ch - 1);
+  const int lx = x - cx * g.gw, ly = y - cy * g.gh;  // < 256 (checked on the host)
+  return ((unsigned long long)(0xFFFF - g.rank[cy * g.cw + cx]) << 48) |
+         ((unsigned long long)val << 16) | ((unsigned long long)(0xFF - ly) << 8) |
+         (unsigned long long)(0xFF - lx);
+}
+
+struct UCaps {
+  int enabled;
+  int rankT, capT, capAfter;
+  const unsigned long long *cellmax;
+  int *cellcount;
+};
+
+__global__ void k_u_cellmax(const unsigned *__restrict__ state, int w, int h, UGrid g,
+                            unsigned long long *__restrict__ cellmax) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const unsigned s = state[(size_t)y * w + x];
+  if (s != 0 && !(s & kAccepted)) atomicMax(&cellmax[ucell(x, y, g)], ukey(s, x, y, g));
+}
+
+__global__ __launch_bounds__(MT) void k_u_round(unsigned *__restrict__ state, int w, int h, int r,
+                                                UGrid g, UCaps caps,
+                                                unsigned *__restrict__ counters, int round) {
+  extern __shared__ __align__(16) unsigned long long lds64[];
+  const int inW = MW + 2 * r, inH = MH + 2 * r;
+  unsigned long long *key = lds64;
+  unsigned long long *rmax = key + inW * inH;
+  unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * MW);
+  unsigned char *racc = acc + inW * inH;
+  __shared__ int any_undecided;
+  const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
+  if (threadIdx.x == 0) any_undecided = 0;
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < inW * inH; i += MT) {
+    const int ty = i / inW, tx = i - ty * inW;
+    const int x = x0 - r + tx, y = y0 - r + ty;
+    unsigned s = 0;
+    if (x >= 0 && x < w && y >= 0 && y < h) s = state[(size_t)y * w + x];
+    const bool a = (s & kAccepted) != 0;
+    key[i] = (s != 0 && !a) ? ukey(s, x, y, g) : 0ull;
+    acc[i] = a;
+    if (s != 0 && !a && tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
+  }
+  if (mine) any_undecided = 1;
+  __syncthreads();
+  if (!any_undecided) return;
+  for (int i = threadIdx.x; i < inH * MW; i += MT) {
+    const int ty = i / MW, tx = i % MW;
+    const unsigned long long *k = key + ty * inW + tx;
+    const unsigned char *a = acc + ty * inW + tx;
+    unsigned long long m = 0;
+    unsigned char o = 0;
+    for (int j = 0; j <= 2 * r; ++j) {
+      m = max(m, k[j]);
+      o |= a[j];
+    }
+    rmax[i] = m;
+    racc[i] = o;
+  }
+  __syncthreads();
+  int left = 0;
+  for (int i = threadIdx.x; i < MH * MW; i += MT) {
+    const int ty = i / MW, tx = i % MW;
+    const unsigned long long own = key[(ty + r) * inW + tx + r];
+    if (own == 0) continue;
+    unsigned long long m = 0;
+    unsigned char o = 0;
+    for (int j = 0; j <= 2 * r; ++j) {
+      m = max(m, rmax[(ty + j) * MW + tx]);
+      o |= racc[(ty + j) * MW + tx];
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    const size_t gi = (size_t)y * w + x;
+    const unsigned val = (unsigned)((own >> 16) & 0x7fffffffu);
+    if (o) {
+      state[gi] = 0;
+    } else if (!caps.enabled) {
+      if (m == own) state[gi] = val | kAccepted; else ++left;
+    } else {
+      const int c = ucell(x, y, g);
+      const int rk = 0xFFFF - (int)(own >> 48);
+      const int cap = rk < caps.rankT ? 0x7fffffff : (rk == caps.rankT ? caps.capT : caps.capAfter);
+      if (caps.cellcount[c] >= cap) {
+        state[gi] = 0;                       // the cell is full (:1253-1254)
+      } else if (m == own && caps.cellmax[c] == own) {
+        state[gi] = val | kAccepted;
+        atomicAdd(&caps.cellcount[c], 1);
+      } else {
+        ++left;
+      }
+    }
+  }
+  if (left) atomicAdd(&counters[round], (unsigned)left);
+}
+
+__global__ void k_u_collect(const unsigned *__restrict__ state, int w, int h, UGrid g,
+                            unsigned long long *__restrict__ keys, unsigned *__restrict__ pos,
+                            unsigned *__restrict__ count, unsigned cap) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const unsigned s = state[(size_t)y * w + x];
+  if (s & kAccepted) {
+    const unsigned i = atomicAdd(count, 1u);
+    if (i < cap) {
+      keys[i] = ukey(s & ~kAccepted, x, y, g);
+      pos[i] = (unsigned)(y * w + x);
+    }
+  }
+}
+
+// rank[i] = number of keys greater than keys[i]
+__global__ __launch_bounds__(256) void k_u_rank(const unsigned long long *__restrict__ keys,
+                                                unsigned n, unsigned *__restrict__ rank) {
+  __shared__ unsigned long long tile[256];
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long own = i < n ? keys[i] : 0ull;
+  unsigned rk = 0;
+  for (unsigned j0 = 0; j0 < n; j0 += 256) {
+    tile[threadIdx.x] = j0 + threadIdx.x < n ? keys[j0 + threadIdx.x] : 0ull;
+    __syncthreads();
+    const unsigned m = min(256u, n - j0);
+    for (unsigned j = 0; j < m; ++j) rk += tile[j] > own;
+    __syncthreads();
+  }
+  if (i < n) rank[i] = rk;
+}
+
+// out[0] = key, out[1] = pos of the entry whose rank is `target`
+__global__ void k_u_find(const unsigned long long *__restrict__ keys,
+                         const unsigned *__restrict__ pos, const unsigned *__restrict__ rank,
+                         unsigned n, unsigned target, unsigned long long *__restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && rank[i] == target) {
+    out[0] = keys[i];
+    out[1] = pos[i];
+  }
+}
+
+// out[2] = number of accepted keys >= T in T's cell
+__global__ void k_u_count_cell(const unsigned long long *__restrict__ keys, unsigned n,
+                               const unsigned long long *__restrict__ T,
+                               unsigned long long *__restrict__ out) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && keys[i] >= T[0] && (keys[i] >> 48) == (T[0] >> 48)) atomicAdd(&out[2], 1ull);
+}
+
+// candidates of lower priority than T go back to "undecided"
+__global__ void k_u_reset(unsigned *__restrict__ state, const unsigned *__restrict__ state0, int w,
+                          int h, UGrid g, const unsigned long long *__restrict__ T) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const unsigned s0 = state0[(size_t)y * w + x];
+  if (s0 != 0 && ukey(s0, x, y, g) < T[0]) state[(size_t)y * w + x] = s0;
+}
+
+// flags[0]: a candidate of lower priority than A exists in A's cell; flags[1]: in a later cell
+__global__ void k_u_tail_flags(const unsigned *__restrict__ state0, int w, int h, UGrid g,
+                               const unsigned long long *__restrict__ A,
+                               unsigned *__restrict__ flags) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= w) return;
+  const unsigned s0 = state0[(size_t)y * w + x];
+  if (s0 == 0) return;
+  const unsigned long long k = ukey(s0, x, y, g);
+  if (k < A[0]) flags[(k >> 48) == (A[0] >> 48) ? 0 : 1] = 1;
+}
+
+__global__ void k_u_assign(const unsigned long long *__restrict__ keys,
+                           const unsigned *__restrict__ pos, const unsigned *__restrict__ rank,
+                           unsigned n, int w, int nslots, float *__restrict__ fx,
+                           float *__restrict__ fy, int *__restrict__ fval) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (int)rank[i] < nslots) {
+    const int s = (int)rank[i];
+    fx[s] = (float)(pos[i] % (unsigned)w);
+    fy[s] = (float)(pos[i] / (unsigned)w);
+    fval[s] = (int)((keys[i] >> 16) & 0x7fffffffu);
+  }
+}
+
+__global__ void k_u_fill(int from, int to, float *__restrict__ fx, float *__restrict__ fy,
+                         int *__restrict__ fval) {
+  const int s = from + blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < to) {
+    fx[s] = -1.0f;
+    fy[s] = -1.0f;
+    fval[s] = GKLT_NOT_FOUND;
+  }
+}
+
+}  // namespace
+
+struct UniScratch {
+  int ncell = 0, w = 0, h = 0;
+  unsigned *state0 = nullptr, *pos = nullptr, *rank = nullptr, *flags = nullptr;
+  unsigned long long *cellmax = nullptr, *tinfo = nullptr;
+  int *cellcount = nullptr;
+  unsigned short *cellrank = nullptr;
+};
+
+void uni_free(UniScratch *u) {
+  if (!u) return;
+  (void)hipFree(u->state0); (void)hipFree(u->pos); (void)hipFree(u->rank); (void)hipFree(u->flags);
+  (void)hipFree(u->cellmax); (void)hipFree(u->tinfo); (void)hipFree(u->cellcount);
+  (void)hipFree(u->cellrank);
+  delete u;
+}
+
+static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
+  UniScratch *u = sc->uni;
+  if (u && (u->ncell < ncell || u->w != sc->w || u->h != sc->h)) {
+    GKLT_HIP(hipDeviceSynchronize());
+    uni_free(u);
+    u = sc->uni = nullptr;
+  }
+  if (!u) {
+    u = new UniScratch();
+    sc->uni = u;
+    u->ncell = ncell; u->w = sc->w; u->h = sc->h;
+    const size_t px = (size_t)sc->w * sc->h;
+    GKLT_HIP(hipMalloc(&u->state0, sizeof(unsigned) * px));
+    GKLT_HIP(hipMalloc(&u->pos, sizeof(unsigned) * (size_t)sc->cap_list));
+    GKLT_HIP(hipMalloc(&u->rank, sizeof(unsigned) * (size_t)sc->cap_list));
+    GKLT_HIP(hipMalloc(&u->flags, 2 * sizeof(unsigned)));
+    GKLT_HIP(hipMalloc(&u->cellmax, sizeof(unsigned long long) * ncell));
+    GKLT_HIP(hipMalloc(&u->tinfo, 4 * sizeof(unsigned long long)));
+    GKLT_HIP(hipMalloc(&u->cellcount, sizeof(int) * ncell));
+    GKLT_HIP(hipMalloc(&u->cellrank, sizeof(unsigned short) * ncell));
+  }
+  *out = u;
+  return 0;
+}
+
+// runs fixpoint rounds until no candidate is undecided
+static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
+                      UCaps caps, int r, int *round_io) {
+  const int w = sc->w, h = sc->h;
+  const size_t lds = (size_t)8 * ((MW + 2 * r) * (MH + 2 * r) + (MH + 2 * r) * MW) +
+                     (size_t)(MW + 2 * r) * (MH + 2 * r) + (size_t)(MH + 2 * r) * MW;
+  if (lds > 160 * 1024) {
+    set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", r, lds);
+    return GKLT_EINVAL;
+  }
+  if (lds > 48 * 1024)
+    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_u_round),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH), pgrid((w + 255) / 256, h);
+  int round = *round_io;
+  bool done = false;
+  while (!done) {
+    const int first = round;
+    {
+      ProfScope ps(ctx, s, GKLT_K_SELECT);
+      for (int b = 0; b < kRoundBatch && round <= kMaxRounds; ++b, ++round) {
+        if (caps.enabled) {
+          GKLT_HIP(hipMemsetAsync(u->cellmax, 0, sizeof(unsigned long long) * u->ncell, s));
+          hipLaunchKernelGGL(k_u_cellmax, pgrid, dim3(256), 0, s, sc->state, w, h, g, u->cellmax);
+        }
+        hipLaunchKernelGGL(k_u_round, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps,
+                           sc->counters, round);
+      }
+    }
+    GKLT_HIP(hipGetLastError());
+    GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
+                            sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    for (int k = first; k < round; ++k)
+      if (sc->h_counters[k] == 0) done = true;
+    if (!done && round > kMaxRounds) {
+      set_error("uniform selection did not converge in %d rounds", kMaxRounds);
+      return GKLT_EHIP;
+    }
+  }
+  *round_io = round;
+  return 0;
+}
+
+// KLTSelectGoodFeaturesUniform (:1318-1338) on device sums; list of capacity `capacity` on device.
+int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int gridW, int gridH,
+                             int n0, int capacity, float *fx, float *fy, int *fval, int *n_out) {
+  const gklt_params &P = ctx->prm;
+  const int w = sc->w, h = sc->h;
+  if (gridW < 1 || gridH < 1 || w / gridW < 1 || h / gridH < 1) {
+    set_error("grid cell %dx%d does not fit a %dx%d image", gridW, gridH, w, h);
+    return GKLT_EINVAL;
+  }
+  const int cw = w / gridW, ch = h / gridH, ncell = cw * ch;  // sizeByGrid, :1330-1331
+  // a clamped remainder-strip cell is at most 2*grid-1 wide; local coordinates take 8 bits
+  if (ncell > 65535 || w - (cw - 1) * gridW > 256 || h - (ch - 1) * gridH > 256 || P.mindist < 0) {
+    set_error("uniform selection supports up to 65535 cells of at most 256x256 px");
+    return GKLT_EINVAL;
+  }
+  const int minFeat = (int)((n0 / (float)ncell) + 0.5);  // :1333
+  const int hw = P.window_width / 2, hh = P.window_height / 2;
+  const int bx = std::max(P.borderx, hw), by = std::max(P.bordery, hh);
+  const int step = P.nSkippedPixels + 1;
+  const int r = P.mindist;  // :1288
+  UniScratch *u;
+  if (int rc = uni_get(sc, ncell, &u)) return rc;
+
+  // initializeGridSequence (:1033-1061): cells by squared distance from the grid centre
+  // (ties, unspecified in the reference's std::sort, by index)
+  {
+    std::vector<std::pair<float, int>> seq(ncell);
+    for (int i = 0; i < ncell; ++i) {
+      const float dY = (float)(i / cw - (float)ch / 2.0);
+      const float dX = (float)(i % cw - (float)cw / 2.0);
+      seq[i] = {dX * dX + dY * dY, i};
+    }
+    std::sort(seq.begin(), seq.end());
+    std::vector<unsigned short> rank(ncell);
+    for (int k = 0; k < ncell; ++k) rank[seq[k].second] = (unsigned short)k;
+    GKLT_HIP(hipMemcpyAsync(u->cellrank, rank.data(), sizeof(unsigned short) * ncell,
+                            hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+  }
+  const UGrid g{gridW, gridH, cw, ch, u->cellrank};
+  const dim3 pgrid((w + 255) / 256, h);
+  const size_t px = (size_t)w * h;
+
+  GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
+  {
+    ProfScope ps(ctx, s, GKLT_K_SELECT);
+    hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->sum[0], sc->sum[1], sc->sum[2],
+                       (const unsigned char *)nullptr, w, h, hw, hh, bx, by, step,
+                       P.min_eigenvalue, 0, sc->state);
+  }
+  GKLT_HIP(hipMemcpyAsync(u->state0, sc->state, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
+
+  int round = 1;
+  UCaps nocaps{0, 0, 0, 0, nullptr, nullptr};
+  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round)) return rc;  // phase A
+
+  auto collect_and_rank = [&](unsigned *n_acc) -> int {
+    GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_u_collect, pgrid, dim3(256), 0, s, sc->state, w, h, g, sc->list, u->pos,
+                       sc->counters, (unsigned)sc->cap_list);
+    GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    *n_acc = sc->h_counters[0];
+    if (*n_acc > (unsigned)sc->cap_list) {
+      set_error("accepted-feature list overflow");
+      return GKLT_ECAPACITY;
+    }
+    if (*n_acc)
+      hipLaunchKernelGGL(k_u_rank, dim3((*n_acc + 255) / 256), dim3(256), 0, s, sc->list, *n_acc,
+                         u->rank);
+    GKLT_HIP(hipGetLastError());
+    return 0;
+  };
+
+  unsigned nacc = 0;
+  if (int rc = collect_and_rank(&nacc)) return rc;
+  int free_slot = 0;
+  if ((int)nacc >= n0 && n0 > 0) {
+    // the slots ran out at T, the candidate that took the last original slot
+    unsigned long long hT[4] = {0, 0, 0, 0};
+    GKLT_HIP(hipMemsetAsync(u->tinfo, 0, sizeof hT, s));
+    hipLaunchKernelGGL(k_u_find, dim3((nacc + 255) / 256), dim3(256), 0, s, sc->list, u->pos,
+                       u->rank, nacc, (unsigned)(n0 - 1), u->tinfo);
+    hipLaunchKernelGGL(k_u_count_cell, dim3((nacc + 255) / 256), dim3(256), 0, s, sc->list, nacc,
+                       u->tinfo, u->tinfo);
+    GKLT_HIP(hipMemcpyAsync(hT, u->tinfo, sizeof hT, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    const int a1 = (int)hT[2];
+    const int tx = (int)(hT[1] % (unsigned)w), ty = (int)(hT[1] / (unsigned)w);
+    const int cellT = std::min(ty / gridH, ch - 1) * cw + std::min(tx / gridW, cw - 1);
+    UCaps caps{1, 0xFFFF - (int)(hT[0] >> 48), std::max(a1, minFeat + 1), minFeat + 1, u->cellmax,
+               u->cellcount};
+    hipLaunchKernelGGL(k_u_reset, pgrid, dim3(256), 0, s, sc->state, u->state0, w, h, g, u->tinfo);
+    GKLT_HIP(hipMemsetAsync(u->cellcount, 0, sizeof(int) * ncell, s));
+    GKLT_HIP(hipMemcpyAsync(u->cellcount + cellT, &a1, sizeof(int), hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
+    GKLT_HIP(hipStreamSynchronize(s));  // a1 is a stack variable
+    round = 1;
+    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round)) return rc;  // phase B
+    if (int rc = collect_and_rank(&nacc)) return rc;
+    // is a grown slot left unfilled?  (see the comment at the top of this section)
+    unsigned long long hA[4] = {0, 0, 0, 0};
+    unsigned hflags[2] = {0, 0};
+    int cntA = 0;
+    GKLT_HIP(hipMemsetAsync(u->flags, 0, sizeof hflags, s));
+    hipLaunchKernelGGL(k_u_find, dim3((nacc + 255) / 256), dim3(256), 0, s, sc->list, u->pos,
+                       u->rank, nacc, nacc - 1, u->tinfo);
+    hipLaunchKernelGGL(k_u_tail_flags, pgrid, dim3(256), 0, s, u->state0, w, h, g, u->tinfo,
+                       u->flags);
+    GKLT_HIP(hipMemcpyAsync(hA, u->tinfo, sizeof hA, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipMemcpyAsync(hflags, u->flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    const int ax = (int)(hA[1] % (unsigned)w), ay = (int)(hA[1] / (unsigned)w);
+    const int cellA = std::min(ay / gridH, ch - 1) * cw + std::min(ax / gridW, cw - 1);
+    GKLT_HIP(hipMemcpyAsync(&cntA, u->cellcount + cellA, sizeof(int), hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    free_slot = (hflags[1] || (hflags[0] && cntA <= minFeat)) ? 1 : 0;
+  }
+  const int total = std::max(n0, (int)nacc + free_slot);  // :1257 grows, :1296-1312 pads
+  if (total > capacity) {
+    set_error("uniform selection needs %d list slots, capacity is %d", total, capacity);
+    return GKLT_ECAPACITY;
+  }
+  {
+    ProfScope ps(ctx, s, GKLT_K_SELECT);
+    if (nacc)
+      hipLaunchKernelGGL(k_u_assign, dim3((nacc + 255) / 256), dim3(256), 0, s, sc->list, u->pos,
+                         u->rank, nacc, w, total, fx, fy, fval);
+    if (total > (int)nacc)
+      hipLaunchKernelGGL(k_u_fill, dim3((total - nacc + 255) / 256), dim3(256), 0, s, (int)nacc,
+                         total, fx, fy, fval);
+  }
+  GKLT_HIP(hipGetLastError());
+  *n_out = total;
+  return 0;
+}
+
 }  // namespace gklt
 
 using namespace gklt;
@@ -490,10 +943,7 @@ extern "C" int gklt_integral_products(gklt_ctx *ctx, gklt_pyramid *py, float *su
 static int resolve_variant(int mode, int variant, int *round2) {
   if (mode != GKLT_SELECT_ALL && mode != GKLT_REPLACE_SOME) return GKLT_EINVAL;
   if (variant == GKLT_VARIANT_UNIFORM) {
-    if (mode == GKLT_SELECT_ALL) {
-      set_error("KLTSelectGoodFeaturesUniform is not built on the GPU yet (SURVEY 8a row S5)");
-      return GKLT_EUNSUPPORTED;
-    }
+    if (mode == GKLT_SELECT_ALL) return 1;  // KLTSelectGoodFeaturesUniform: own path
     variant = GKLT_VARIANT_PLAIN;  // KLTReplaceLostFeaturesUniform runs the plain replace (:1353)
   }
   if (variant != GKLT_VARIANT_PLAIN && variant != GKLT_VARIANT_ROUND2) return GKLT_EINVAL;
@@ -506,13 +956,35 @@ extern "C" int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *su
                            const float *sumyy, const float *sumxy, int width, int height,
                            int *nFeatures, int capacity, float *x, float *y, int *val, int gridW,
                            int gridH) {
-  (void)gridW;
-  (void)gridH;
   if (!ctx || !sumxx || !sumyy || !sumxy || !nFeatures || width < 1 || height < 1) return GKLT_EINVAL;
   const int n = *nFeatures;
-  if (n < 0 || n > capacity || (n > 0 && (!x || !y || !val))) return GKLT_EINVAL;
+  if (n < 0 || n > capacity || (capacity > 0 && (!x || !y || !val))) return GKLT_EINVAL;
   int round2 = 0;
-  if (int rc = resolve_variant(mode, variant, &round2)) return rc;
+  const int rv = resolve_variant(mode, variant, &round2);
+  if (rv < 0) return rv;
+  if (rv == 1) {  // KLTSelectGoodFeaturesUniform (:1318-1338)
+    GKLT_HIP(hipSetDevice(ctx->device));
+    SelScratch *sc;
+    if (int rc = sel_get(ctx, width, height, n, &sc)) return rc;
+    if (!ctx->scratch_list || ctx->scratch_list->capacity < capacity) {
+      if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
+      ctx->scratch_list = nullptr;
+      if (int rc = gklt_flist_create(ctx, std::max(capacity, 4096), &ctx->scratch_list)) return rc;
+    }
+    gklt_flist *fl = ctx->scratch_list;
+    hipStream_t s = ctx->s_trk;
+    const size_t sb = sizeof(float) * (size_t)(width + 1) * (height + 1);
+    const float *src[3] = {sumxx, sumyy, sumxy};
+    for (int i = 0; i < 3; ++i)
+      GKLT_HIP(hipMemcpyAsync(sc->sum[i], src[i], sb, hipMemcpyHostToDevice, s));
+    int n_out = n;
+    if (int rc = select_uniform_on_device(ctx, s, sc, gridW, gridH, n, capacity, fl->x, fl->y,
+                                          fl->val, &n_out))
+      return rc;
+    fl->n = n_out;
+    *nFeatures = n_out;
+    return gklt_flist_download(ctx, fl, x, y, val);
+  }
   if (n == 0) return 0;
   if (mode == GKLT_REPLACE_SOME && gklt_count_remaining(n, val) == n) return 0;  // :442-447
   GKLT_HIP(hipSetDevice(ctx->device));
@@ -535,12 +1007,32 @@ extern "C" int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *su
 }
 
 extern "C" int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *py, int mode, int variant,
-                                        gklt_flist *fl) {
+                                        gklt_flist *fl, int gridW, int gridH) {
   if (!ctx || !py || !fl || py->ctx != ctx || fl->ctx != ctx) return GKLT_EINVAL;
   int round2 = 0;
-  if (int rc = resolve_variant(mode, variant, &round2)) return rc;
-  if (fl->n == 0) return 0;
+  const int rv = resolve_variant(mode, variant, &round2);
+  if (rv < 0) return rv;
   GKLT_HIP(hipSetDevice(ctx->device));
+  if (rv == 1) {
+    if (!py->has_ready) {
+      set_error("selecting on a pyramid that was never built");
+      return GKLT_EINVAL;
+    }
+    SelScratch *sc;
+    if (int rc = sel_get(ctx, py->lv[0].w, py->lv[0].h, fl->n, &sc)) return rc;
+    hipStream_t s = ctx->s_trk;
+    GKLT_HIP(hipStreamWaitEvent(s, py->ready, 0));
+    if (int rc = select_integrals_from_pyramid(ctx, s, py, sc)) return rc;
+    int n_out = fl->n;
+    if (int rc = select_uniform_on_device(ctx, s, sc, gridW, gridH, fl->n, fl->capacity, fl->x,
+                                          fl->y, fl->val, &n_out))
+      return rc;
+    fl->n = n_out;
+    GKLT_HIP(hipEventRecord(py->consumed, s));
+    py->has_consumed = true;
+    return 0;
+  }
+  if (fl->n == 0) return 0;
   if (!py->has_ready) {
     set_error("selecting on a pyramid that was never built");
     return GKLT_EINVAL;

@@ -429,5 +429,5 @@ def select_features(ctx, mode, variant, sumxx, sumyy, sumxy, nFeatures, x=None, 
     return fx[: n.value].copy(), fy[: n.value].copy(), fv[: n.value].copy()
 
 
-def select_from_pyramid(ctx, pyr, mode, variant, fl):
-    _check(lib().gklt_select_from_pyramid(ctx.h, pyr.h, mode, variant, fl.h))
+def select_from_pyramid(ctx, pyr, mode, variant, fl, grid=(20, 20)):
+    _check(lib().gklt_select_from_pyramid(ctx.h, pyr.h, mode, variant, fl.h, grid[0], grid[1]))

@@ -160,16 +160,19 @@ int gklt_integral_products(gklt_ctx *ctx, gklt_pyramid *pyr, float *sumDxx, floa
 /* KLTSelectGoodFeatures / KLTReplaceLostFeatures (selectGoodFeatures.hpp:424-449), ...2
  * (:997-1022) and KLTReplaceLostFeaturesUniform (:1341-1355, which runs the plain replace) on host
  * integral images and a host SoA list of *nFeatures entries, updated in place.  Ties between
- * equal scores, unspecified in the reference (qsort), are ordered y ascending then x ascending.
- * KLTSelectGoodFeaturesUniform (mode ALL, variant UNIFORM) returns GKLT_EUNSUPPORTED for now;
- * gridW/gridH (the cell size in pixels, selectGoodFeatures.hpp:28) are reserved for it. */
+ * equal scores, unspecified in the reference (qsort / std::sort), are ordered y ascending then x
+ * ascending; grid cells at equal distance from the centre by index.
+ * KLTSelectGoodFeaturesUniform (mode ALL, variant UNIFORM, selectGoodFeatures.hpp:1318-1338)
+ * takes the cell size in pixels in gridW/gridH (the reference's global gridSize, :28) and may
+ * GROW the list: *nFeatures is updated and x/y/val must hold `capacity` entries (the reference
+ * allocates 100x, KLTUtil.cpp:53-55); GKLT_ECAPACITY if it would grow beyond that. */
 int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *sumDxx, const float *sumDyy,
                 const float *sumDxy, int width, int height, int *nFeatures, int capacity, float *x,
                 float *y, int *val, int gridW, int gridH);
 /* Same selection with the integral images computed on the device from pyramid level 0 and the
  * list resident on the device; asynchronous apart from the convergence polls. */
 int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *pyr, int mode, int variant,
-                             gklt_flist *fl);
+                             gklt_flist *fl, int gridW, int gridH);
 
 /* ---- frame pipeline: PyramidBuffer (System.h:30-56) + the call pattern of System::Track ---- */
 

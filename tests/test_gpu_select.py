@@ -106,10 +106,31 @@ def test_replace_lost_matches_oracle(klt, ok, gpu_ctx, variant):
     assert (same[0] == x).all() and (same[2] == 0).all()
 
 
-def test_select_uniform_is_reported_unsupported(klt, gpu_ctx):
-    s = [np.zeros((33, 33), np.float32)] * 3
-    with pytest.raises(klt.GkltError, match="not built on the GPU"):
-        klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *s, 10)
+@pytest.mark.parametrize("H,W,n,grid,mindist,min_eig,border", [
+    (96, 128, 10, (32, 32), 5, 20, 8),       # grows far beyond 10 slots
+    (135, 240, 60, (20, 20), 6, 50, 10),     # remainder strips in both directions (clamped cells)
+    (135, 240, 4000, (20, 20), 6, 50, 10),   # slots never run out: NOT_FOUND tail
+    (270, 480, 300, (32, 32), 10, 100, 24),  # BASELINE C5 geometry at quarter size
+    (200, 333, 90, (50, 40), 12, 30, 10),
+    (96, 128, 1, (64, 48), 3, 200, 8),
+])
+def test_select_uniform_matches_oracle(klt, ok, gpu_ctx, H, W, n, grid, mindist, min_eig, border):
+    """KLTSelectGoodFeaturesUniform: per-cell selection, centre-out, may GROW nFeatures (:1257)."""
+    _, sums = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    kw = dict(window=7, levels=2, border=border, mindist=mindist, min_eigenvalue=min_eig)
+    gpu_ctx.set_params(klt.make_params(**kw))
+    cap = max(100 * n, 4096)
+    got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *sums, n, grid=grid, capacity=cap)
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, n, grid=grid,
+                             capacity=cap)
+    _same_lists(got, ref)
+
+
+def test_select_uniform_capacity_error(klt, ok, gpu_ctx):
+    _, sums = _sums(klt, ok, gpu_ctx, _frame(96, 128))
+    gpu_ctx.set_params(klt.make_params(window=7, levels=2, border=8, mindist=5, min_eigenvalue=20))
+    with pytest.raises(klt.GkltError, match="capacity"):
+        klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *sums, 10, grid=(32, 32), capacity=12)
 
 
 def test_select_from_pyramid_device_list(klt, ok, gpu_ctx):
@@ -152,3 +173,10 @@ def test_full_size_1080p_select(klt, ok, gpu_ctx):
     ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
     _same_lists(got, ref)
     assert (got[2] > 0).all()                           # a textured 1080p frame fills 4000 slots
+    # BASELINE config 5: Uniform flavour, 32x32 px cells, bordery >= 24 (SURVEY A.3 hazard 1)
+    kw["border"] = 64
+    gpu_ctx.set_params(klt.make_params(**kw))
+    got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *sums, n, grid=(32, 32))
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, n, grid=(32, 32))
+    _same_lists(got, ref)
+    assert len(got[2]) > n
