@@ -402,14 +402,14 @@ extern "C" int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out) 
   fl->capacity = capacity;
   // one allocation [x | y | val], each `capacity` long, so a frame's results leave in one copy
   if (hipMalloc(&fl->x, 3 * sizeof(float) * (size_t)capacity) != hipSuccess ||
-      hipMalloc(&fl->stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc(&fl->stats, 2 * GKLT_STAT_SHARDS * sizeof(unsigned long long)) != hipSuccess) {
     set_error("hipMalloc of a %d-feature list failed", capacity);
     gklt_flist_destroy(fl);
     return GKLT_ENOMEM;
   }
   fl->y = fl->x + capacity;
   fl->val = reinterpret_cast<int *>(fl->x + 2 * (size_t)capacity);
-  GKLT_HIP(hipMemsetAsync(fl->stats, 0, 2 * sizeof(unsigned long long), ctx->s_trk));
+  GKLT_HIP(hipMemsetAsync(fl->stats, 0, 2 * GKLT_STAT_SHARDS * sizeof(unsigned long long), ctx->s_trk));
   *out = fl;
   return 0;
 }
@@ -475,12 +475,14 @@ extern "C" int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked
                                 uint64_t *iterations, int reset) {
   if (!ctx || !fl) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
-  unsigned long long h[2];
+  unsigned long long h[2 * GKLT_STAT_SHARDS];
   GKLT_HIP(hipMemcpyAsync(h, fl->stats, sizeof h, hipMemcpyDeviceToHost, ctx->s_trk));
   if (reset) GKLT_HIP(hipMemsetAsync(fl->stats, 0, sizeof h, ctx->s_trk));
   GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
-  if (tracked) *tracked = h[0];
-  if (iterations) *iterations = h[1];
+  unsigned long long t = 0, it = 0;
+  for (int i = 0; i < GKLT_STAT_SHARDS; ++i) { t += h[2 * i]; it += h[2 * i + 1]; }
+  if (tracked) *tracked = t;
+  if (iterations) *iterations = it;
   return 0;
 }
 
@@ -611,5 +613,12 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
   if (!ctx) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   GKLT_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+// 0 = one feature per wavefront (default), 1 = one feature per 8-lane slice (kept for A/B runs)
+extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
+  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  ctx->track_impl = impl;
   return 0;
 }

@@ -26,6 +26,7 @@ void set_error(const char *fmt, ...);
 // Half of a symmetric (sym=+1) or antisymmetric (sym=-1) convolution kernel:
 // k[0] = centre tap, k[j] = tap at offset +j (tap at -j is sym*k[j]).
 constexpr int kMaxRadius = GKLT_MAX_KERNEL_WIDTH / 2;  // 35
+#define GKLT_STAT_SHARDS 256  // tracker counters are sharded over this many (tracked, iters) pairs
 struct Taps {
   int r;
   int sym;
@@ -62,6 +63,7 @@ struct gklt_ctx {
   double *d_norm = nullptr, *d_vec = nullptr;
   int d_nv_capacity = 0;
   // profiling
+  int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;
   struct Span {
     hipEvent_t a, b;
@@ -89,7 +91,7 @@ struct gklt_flist {
   int capacity = 0, n = 0;
   float *x = nullptr, *y = nullptr;
   int *val = nullptr;
-  unsigned long long *stats = nullptr;  // [0] tracked, [1] iterations
+  unsigned long long *stats = nullptr;  // GKLT_STAT_SHARDS x {tracked, iterations}
 };
 
 namespace gklt {

@@ -42,6 +42,7 @@ struct TrackArgs {
 };
 
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
+constexpr int kStatShards = GKLT_STAT_SHARDS;
 
 struct Bilin {
   int xt, yt;
@@ -331,8 +332,213 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 #pragma unroll
     for (int o = 32; o >= SL; o >>= 1) it += __shfl_xor(it, o);
     if (lane == 0) {
-      atomicAdd(&stats[0], (unsigned long long)__popcll(m));
-      atomicAdd(&stats[1], (unsigned long long)it);
+      unsigned long long *sh = stats + 2 * (blockIdx.x & (kStatShards - 1));
+      atomicAdd(&sh[0], (unsigned long long)__popcll(m));
+      atomicAdd(&sh[1], (unsigned long long)it);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_track_w: ONE FEATURE PER WAVEFRONT.  The window's elements are spread over all 64 lanes
+// (element i -> lane i % 64), so sampling is 8x more parallel than in the slice kernel above and
+// every branch (levels, Newton iterations, status) is wave-uniform.  The reference's summation
+// order is kept by a two-step reduction through LDS: the per-element products are written to
+// LDS, lane (q, k) of the first 40 lanes then adds chain k of quantity q (elements k, k+8, ...)
+// in element order -- the AVX lane partial of LK.hpp:133-137,154-157 -- and lanes 0..4 add the 8
+// partials of their quantity left to right (LK.hpp:143-145,163-164).  The five totals leave as
+// wave-uniform scalars (v_readlane).  EPL = window elements per lane (compile time).
+template <int EPL>
+__global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__ fx,
+                                                float *__restrict__ fy, int *__restrict__ fval,
+                                                const double *__restrict__ invk,
+                                                double *__restrict__ norm3,
+                                                double *__restrict__ vec3,
+                                                unsigned long long *__restrict__ stats) {
+  extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40]
+  const int lane = threadIdx.x;
+  const int f = blockIdx.x;
+  const int ww = a.ww, wh = a.wh, npix = ww * wh;
+  const int NA = SL * ((npix + SL) / SL);  // alignedPatchSize (LK.hpp:448)
+  const int nec = NA / SL;                 // elements per AVX-lane chain
+  const int hw = ww / 2, hh = wh / 2;
+  float *prod = lds;
+  float *part = lds + 5 * NA;
+
+  const int val0 = fval[f];
+  float xloc = fx[f], yloc = fy[f];
+  if (val0 < 0) {  // LK.hpp:830: lost features are not touched
+    if (a.mirror && lane == 0) {
+      a.mirror[f] = xloc;
+      a.mirror[a.mirror_stride + f] = yloc;
+      reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = val0;
+    }
+    return;
+  }
+  // element -> texel offset inside the window (tail elements clamp to the last pixel, value 0)
+  int eoff_x[EPL], eoff_y[EPL];
+  bool evalid[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) {
+    const int i = e * 64 + lane;
+    const int ic = min(i, npix - 1);
+    eoff_y[e] = ic / ww;
+    eoff_x[e] = ic - eoff_y[e] * ww;
+    evalid[e] = i < npix;
+  }
+  // ordered reduction of nq quantities whose per-element products sit in prod[q][0..NA)
+  auto reduce = [&](int nq, float (&tot)[5]) {
+    __syncthreads();
+    if (lane < nq * SL) {
+      const int q = lane >> 3, k = lane & 7;
+      const float *p = prod + q * NA + k;
+      float acc = 0.f;
+      for (int j = 0; j < nec; ++j) acc = acc + p[j * SL];
+      part[lane] = acc;
+    }
+    __syncthreads();
+    float t = 0.f;
+    if (lane < nq) {
+      const float4 lo = *reinterpret_cast<const float4 *>(part + lane * SL);
+      const float4 hi = *reinterpret_cast<const float4 *>(part + lane * SL + 4);
+      t = ((((((lo.x + lo.y) + lo.z) + lo.w) + hi.x) + hi.y) + hi.z) + hi.w;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), q));
+  };
+
+  for (int r = 0; r < a.nlevels; ++r) { xloc /= a.ss; yloc /= a.ss; }  // LK.hpp:837-839
+  float xo = xloc, yo = yloc;
+  int v = GKLT_TRACKED;
+  int iters_total = 0;
+
+  for (int r = a.nlevels - 1; r >= 0; --r) {  // LK.hpp:859-881
+    xloc *= a.ss; yloc *= a.ss;
+    xo *= a.ss; yo *= a.ss;
+    // ---- _trackFeature, LK.hpp:413-669 ----
+    const TrackLevel L = a.lv[r];
+    const int nc = L.nc, nr = L.nr;
+    int status = GKLT_TRACKED, iteration = 0;
+    const float x1 = xloc, y1 = yloc;
+    float x2 = xo, y2 = yo;
+
+    if (window_oob(x1, y1, hw, hh, nc, nr) || window_oob(x2, y2, hw, hh, nc, nr)) {
+      status = GKLT_OOB;  // first pass of the do-loop, :558-564
+    } else {
+      Bilin b1 = bilinear_weight(x1, y1);
+      clamp_origin(b1, hw, hh, nc, nr);
+      const Texel *o1 = L.t1 + (size_t)(b1.yt - hh) * nc + (b1.xt - hw);
+      Bilin b2 = bilinear_weight(x2, y2);  // :568-572
+      clamp_origin(b2, hw, hh, nc, nr);
+      const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+      float3 T1[EPL], S2[EPL];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) T1[e] = sample(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        if (!evalid[e]) T1[e] = make_float3(0.f, 0.f, 0.f);
+
+      float dx, dy;
+      for (;;) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int i = e * 64 + lane;
+          const float3 s = evalid[e] ? S2[e] : make_float3(0.f, 0.f, 0.f);
+          const float diff = T1[e].x - s.x;  // computeImageDiff :110-116
+          const float gx = T1[e].y + s.y;    // computeImageSum  :118-125
+          const float gy = T1[e].z + s.z;
+          if (i < NA) {
+            prod[0 * NA + i] = gx * gx;      // compute2X2GradientMatrix :127-146
+            prod[1 * NA + i] = gy * gy;
+            prod[2 * NA + i] = gx * gy;
+            prod[3 * NA + i] = gx * diff;    // compute2X1ErrorVector :148-166
+            prod[4 * NA + i] = gy * diff;
+          }
+        }
+        float tot[5];
+        reduce(5, tot);
+        const float gxx = tot[0], gyy = tot[1], gxy = tot[2];
+        const float ex = tot[3] * a.step_factor, ey = tot[4] * a.step_factor;
+
+        const float det = gxx * gyy - gxy * gxy;  // _solveEquation :168-183
+        if (det < a.min_det) { status = GKLT_SMALL_DET; break; }
+        dx = (gyy * ex - gxy * ey) / det;
+        dy = (gxx * ey - gxy * ex) / det;
+        status = GKLT_TRACKED;
+        x2 += dx; y2 += dy;
+        ++iteration;
+        if (!((fabsf(dx) >= a.min_disp || fabsf(dy) >= a.min_disp) && iteration < a.max_iter))
+          break;  // :615
+        if (window_oob(x2, y2, hw, hh, nc, nr)) { status = GKLT_OOB; break; }  // next pass :558
+        b2 = bilinear_weight(x2, y2);
+        clamp_origin(b2, hw, hh, nc, nr);
+        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+      }
+
+      if (window_oob(x2, y2, hw, hh, nc, nr)) status = GKLT_OOB;  // :620-623
+
+      // residue (:626-636), level 0 only: see k_track
+      if (status == GKLT_TRACKED && r == 0) {
+        b2 = bilinear_weight(x2, y2);
+        clamp_origin(b2, hw, hh, nc, nr);
+        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        __syncthreads();  // chain sums of the last iteration have been read
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+          const int i = e * 64 + lane;
+          const float sI = sample_i(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+          if (i < NA) prod[i] = evalid[e] ? fabsf(T1[e].x - sI) : 0.f;  // :193-208
+        }
+        float tot[5];
+        reduce(1, tot);
+        if (tot[0] / (ww * wh) > a.max_residue) status = GKLT_LARGE_RESIDUE;
+      }
+    }
+    iters_total += iteration;
+    xo = x2; yo = y2;
+    // return value precedence, :655-667
+    if (status == GKLT_SMALL_DET || status == GKLT_OOB || status == GKLT_LARGE_RESIDUE) v = status;
+    else v = iteration >= a.max_iter ? GKLT_MAX_ITERATIONS : GKLT_TRACKED;
+    if (v == GKLT_SMALL_DET || v == GKLT_OOB) break;  // :879-880
+    __syncthreads();  // prod is rewritten by the next level
+  }
+
+  // ---- record feature, LK.hpp:886-915 ----
+  const bool oob = xo < a.borderx || xo > a.w0 - 1 - a.borderx || yo < a.bordery ||
+                   yo > a.h0 - 1 - a.bordery;  // _outOfBounds :185-191
+  const int out = (v == GKLT_OOB || oob) ? GKLT_OOB : v;
+  const bool tracked = out == GKLT_TRACKED;
+  if (lane == 0) {
+    const float ox = tracked ? xo : -1.0f, oy = tracked ? yo : -1.0f;
+    fx[f] = ox;
+    fy[f] = oy;
+    fval[f] = out;
+    if (a.mirror) {
+      a.mirror[f] = ox;
+      a.mirror[a.mirror_stride + f] = oy;
+      reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = out;
+    }
+    if (tracked && a.do_epilogue) {  // bearing vectors, LK.hpp:1019-1035 (fp64)
+      const double px = (double)xo, py = (double)yo;
+      double q[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) q[i] = (invk[3 * i] * px + invk[3 * i + 1] * py) + invk[3 * i + 2];
+      const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
+      double nv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { nv[i] = q[i] / nn; norm3[3 * (size_t)f + i] = nv[i]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) vec3[3 * (size_t)f + i] = nv[i] / nv[2];
+    }
+    if (stats) {  // sharded: thousands of adds to one word would serialise at the memory side
+      unsigned long long *sh = stats + 2 * (f & (kStatShards - 1));
+      if (tracked) atomicAdd(&sh[0], 1ull);
+      atomicAdd(&sh[1], (unsigned long long)iters_total);
     }
   }
 }
@@ -378,7 +584,20 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
 
   const dim3 grid((n + 7) / 8), block(64);
   ProfScope ps(ctx, s, GKLT_K_TRACK);
-  if (a.ww == 7 && a.wh == 7) {
+  const int NA = 8 * ((a.ww * a.wh + 8) / 8);
+  const int epl = (NA + 63) / 64;
+  const size_t wlds = sizeof(float) * (size_t)(5 * NA + 40);
+#define GKLT_TRACK_W(E)                                                                       \
+  hipLaunchKernelGGL((k_track_w<E>), dim3(n), block, wlds, s, a, x, y, val, d_invk, d_norm, d_vec, \
+                     stats)
+  if (ctx->track_impl == 0 && epl <= 16 && wlds <= 48 * 1024) {  // one feature per wavefront
+    if (epl <= 1) GKLT_TRACK_W(1);
+    else if (epl <= 2) GKLT_TRACK_W(2);
+    else if (epl <= 4) GKLT_TRACK_W(4);
+    else if (epl <= 8) GKLT_TRACK_W(8);
+    else GKLT_TRACK_W(16);
+#undef GKLT_TRACK_W
+  } else if (a.ww == 7 && a.wh == 7) {
     hipLaunchKernelGGL((k_track<7, 7>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
   } else if (a.ww == 11 && a.wh == 11) {
     hipLaunchKernelGGL((k_track<11, 11>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);

@@ -154,6 +154,10 @@ class Context:
     def sync(self):
         _check(lib().gklt_sync(self.h))
 
+    def set_track_impl(self, impl):
+        """0 = one feature per wavefront (default), 1 = one feature per 8-lane slice."""
+        _check(lib().gklt_ctx_set_track_impl(self.h, int(impl)))
+
     def close(self):
         if self.h:
             lib().gklt_ctx_destroy(self.h)

@@ -216,6 +216,11 @@ int gklt_device_synchronize(gklt_ctx *ctx);
 
 /* ---- measurement ---- */
 
+/* Tracker mapping: 0 = one feature per wavefront (default), 1 = one feature per 8-lane slice.
+ * Both produce identical results; kept selectable for A/B timing. */
+int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
+
+
 enum {
   GKLT_K_SMOOTH0 = 0, /* u8 -> smoothed level 0 */
   GKLT_K_DOWN = 1,    /* pre-decimation smooth + 2x decimation (all levels) */

@@ -50,6 +50,8 @@ def _assert_same(got, ref):
     (21, 2, 200, 320, 300),     # as-shipped window: generic LDS path
     (5, 3, 135, 240, 333),      # generic path, n not a multiple of 8
     (9, 2, 135, 240, 64),
+    (31, 2, 200, 320, 40),      # 961 px: 16 window elements per lane
+    (33, 1, 200, 320, 24),      # beyond the wave-per-feature kernel: slice kernel with LDS template
 ])
 def test_track_exact(klt, ok, gpu_ctx, window, levels, H, W, n):
     f = _stream(H, W, 2)
@@ -59,6 +61,22 @@ def test_track_exact(klt, ok, gpu_ctx, window, levels, H, W, n):
     got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[1], window, levels, x, y, val)
     _assert_same(got, ref)
     assert (got[2] == 0).mean() > 0.9  # the synthetic pan is well inside the capture range
+
+
+@pytest.mark.parametrize("window,levels", [(7, 4), (11, 3), (21, 2), (5, 3)])
+def test_track_slice_kernels_agree(klt, ok, gpu_ctx, window, levels):
+    """The alternative mapping (one feature per 8-lane slice) gives the same bits."""
+    H, W, n = 270, 480, 500
+    f = _stream(H, W, 2)
+    p = ok.make_params(window=window, levels=levels)
+    x, y = synth.lattice_seeds(H, W, n, p.borderx)
+    val = np.zeros(len(x), np.int32)
+    gpu_ctx.set_track_impl(1)
+    try:
+        got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[1], window, levels, x, y, val)
+    finally:
+        gpu_ctx.set_track_impl(0)
+    _assert_same(got, ref)
 
 
 def test_track_rectangular_window_and_even_fix(klt, ok, gpu_ctx):
