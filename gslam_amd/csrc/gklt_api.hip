@@ -616,9 +616,10 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
   return 0;
 }
 
-// 0 = one feature per wavefront (default), 1 = one feature per 8-lane slice (kept for A/B runs)
+// 0 = one feature per wavefront, LDS footprint staging chosen by window size (default);
+// 1 = one feature per 8-lane slice; 2 / 3 = one feature per wavefront without / with staging
 extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
-  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->track_impl = impl;
   return 0;
 }

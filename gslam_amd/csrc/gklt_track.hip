@@ -13,6 +13,8 @@
 // template patch (I, gx, gy of frame 1) lives in registers for the instantiated window sizes
 // and in LDS for the generic kernel.  Each bilinear tap is one 16-byte load of an (I,gx,gy,0)
 // texel (layout written by gklt_pyramid.hip).
+#include <algorithm>
+
 #include "gklt_internal.h"
 
 namespace gklt {
@@ -348,22 +350,30 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // in element order -- the AVX lane partial of LK.hpp:133-137,154-157 -- and lanes 0..4 add the 8
 // partials of their quantity left to right (LK.hpp:143-145,163-164).  The five totals leave as
 // wave-uniform scalars (v_readlane).  EPL = window elements per lane (compile time).
-template <int EPL>
+// STAGE: the (w+1) x (h+1) texel footprint of a pass is fetched once (one 12-byte gather per
+// footprint texel) into LDS and the four bilinear taps of every element are read from there,
+// instead of four gathers per element.
+// FPL = footprint texels per lane (0 = no staging).
+template <int EPL, int FPL>
 __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
                                                 const double *__restrict__ invk,
                                                 double *__restrict__ norm3,
                                                 double *__restrict__ vec3,
                                                 unsigned long long *__restrict__ stats) {
-  extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40]
+  extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40] | fp[NF] (float4)
   const int lane = threadIdx.x;
   const int f = blockIdx.x;
   const int ww = a.ww, wh = a.wh, npix = ww * wh;
   const int NA = SL * ((npix + SL) / SL);  // alignedPatchSize (LK.hpp:448)
   const int nec = NA / SL;                 // elements per AVX-lane chain
   const int hw = ww / 2, hh = wh / 2;
+  constexpr bool STAGE = FPL > 0;
+  constexpr int FP = STAGE ? FPL : 1;
   float *prod = lds;
   float *part = lds + 5 * NA;
+  float4 *fp = reinterpret_cast<float4 *>(part + 40);
+  const int FW = ww + 1, NF = FW * (wh + 1);
 
   const int val0 = fval[f];
   float xloc = fx[f], yloc = fy[f];
@@ -386,6 +396,37 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
     eoff_x[e] = ic - eoff_y[e] * ww;
     evalid[e] = i < npix;
   }
+  // footprint texel j = e*64 + lane -> offset inside the footprint (clamped past the end)
+  int foff_x[FP], foff_y[FP];
+  if (STAGE) {
+#pragma unroll
+    for (int e = 0; e < FP; ++e) {
+      const int jc = min(e * 64 + lane, NF - 1);
+      foff_y[e] = jc / FW;
+      foff_x[e] = jc - foff_y[e] * FW;
+    }
+  }
+  auto fp_load = [&](const Texel *o, int nc, float3 (&t)[FP]) {
+#pragma unroll
+    for (int e = 0; e < FP; ++e) {
+      const Texel v = o[foff_y[e] * nc + foff_x[e]];
+      t[e] = make_float3(v.x, v.y, v.z);
+    }
+  };
+  auto fp_store = [&](const float3 (&t)[FP]) {
+#pragma unroll
+    for (int e = 0; e < FP; ++e)
+      if (e * 64 + lane < NF) fp[e * 64 + lane] = make_float4(t[e].x, t[e].y, t[e].z, 0.f);
+  };
+  auto fp_sample = [&](int e, const Bilin &b) {
+    const float4 *q = fp + eoff_y[e] * FW + eoff_x[e];
+    const float4 t00 = q[0], t01 = q[1], t10 = q[FW], t11 = q[FW + 1];
+    float3 o;
+    o.x = (t00.x * b.w0 + t01.x * b.w1) + (t10.x * b.w2 + t11.x * b.w3);
+    o.y = (t00.y * b.w0 + t01.y * b.w1) + (t10.y * b.w2 + t11.y * b.w3);
+    o.z = (t00.z * b.w0 + t01.z * b.w1) + (t10.z * b.w2 + t11.z * b.w3);
+    return o;
+  };
   // ordered reduction of nq quantities whose per-element products sit in prod[q][0..NA)
   auto reduce = [&](int nq, float (&tot)[5]) {
     __syncthreads();
@@ -393,7 +434,15 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
       const int q = lane >> 3, k = lane & 7;
       const float *p = prod + q * NA + k;
       float acc = 0.f;
-      for (int j = 0; j < nec; ++j) acc = acc + p[j * SL];
+      // groups of 8 independent LDS reads (clamped index), then the adds in element order
+      for (int j0 = 0; j0 < nec; j0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[min(j0 + u, nec - 1) * SL];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j0 + u < nec) acc = acc + t[u];
+      }
       part[lane] = acc;
     }
     __syncthreads();
@@ -433,10 +482,26 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
       clamp_origin(b2, hw, hh, nc, nr);
       const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
       float3 T1[EPL], S2[EPL];
+      if (STAGE) {
+        float3 f1[FP], f2[FP];
+        fp_load(o1, nc, f1);  // both footprints are in flight together
+        fp_load(o2, nc, f2);
+        __syncthreads();      // previous readers of fp are done
+        fp_store(f1);
+        __syncthreads();
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) T1[e] = sample(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
+        for (int e = 0; e < EPL; ++e) T1[e] = fp_sample(e, b1);
+        __syncthreads();
+        fp_store(f2);
+        __syncthreads();
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+        for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) T1[e] = sample(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+      }
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
         if (!evalid[e]) T1[e] = make_float3(0.f, 0.f, 0.f);
@@ -476,8 +541,18 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
         b2 = bilinear_weight(x2, y2);
         clamp_origin(b2, hw, hh, nc, nr);
         o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        if (STAGE) {
+          float3 f2[FP];
+          fp_load(o2, nc, f2);
+          __syncthreads();
+          fp_store(f2);
+          __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+          for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+        }
       }
 
       if (window_oob(x2, y2, hw, hh, nc, nr)) status = GKLT_OOB;  // :620-623
@@ -487,12 +562,24 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
         b2 = bilinear_weight(x2, y2);
         clamp_origin(b2, hw, hh, nc, nr);
         o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        float sI[EPL];
+        if (STAGE) {
+          float3 f2[FP];
+          fp_load(o2, nc, f2);
+          __syncthreads();
+          fp_store(f2);
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sI[e] = fp_sample(e, b2).x;
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) sI[e] = sample_i(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+        }
         __syncthreads();  // chain sums of the last iteration have been read
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const int i = e * 64 + lane;
-          const float sI = sample_i(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
-          if (i < NA) prod[i] = evalid[e] ? fabsf(T1[e].x - sI) : 0.f;  // :193-208
+          if (i < NA) prod[i] = evalid[e] ? fabsf(T1[e].x - sI[e]) : 0.f;  // :193-208
         }
         float tot[5];
         reduce(1, tot);
@@ -585,17 +672,33 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
   const dim3 grid((n + 7) / 8), block(64);
   ProfScope ps(ctx, s, GKLT_K_TRACK);
   const int NA = 8 * ((a.ww * a.wh + 8) / 8);
-  const int epl = (NA + 63) / 64;
-  const size_t wlds = sizeof(float) * (size_t)(5 * NA + 40);
-#define GKLT_TRACK_W(E)                                                                       \
-  hipLaunchKernelGGL((k_track_w<E>), dim3(n), block, wlds, s, a, x, y, val, d_invk, d_norm, d_vec, \
-                     stats)
-  if (ctx->track_impl == 0 && epl <= 16 && wlds <= 48 * 1024) {  // one feature per wavefront
-    if (epl <= 1) GKLT_TRACK_W(1);
-    else if (epl <= 2) GKLT_TRACK_W(2);
-    else if (epl <= 4) GKLT_TRACK_W(4);
-    else if (epl <= 8) GKLT_TRACK_W(8);
-    else GKLT_TRACK_W(16);
+  const int NF = (a.ww + 1) * (a.wh + 1);
+  // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
+  // 19.2 us at C2, 11x11 86 / 98 us at C3, 21x21 67 / 39 us at Cship); track_impl 2 / 3 force it.
+  const bool stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && a.ww * a.wh >= 200);
+  const int epl = (NA + 63) / 64, fpl = (NF + 63) / 64;
+  const size_t wlds = sizeof(float) * (size_t)(5 * NA + 40) + (stage ? sizeof(float4) * (size_t)NF : 0);
+#define GKLT_TRACK_W(E, F)                                                                     \
+  hipLaunchKernelGGL((k_track_w<E, F>), dim3(n), block, wlds, s, a, x, y, val, d_invk, d_norm,   \
+                     d_vec, stats)
+  if (ctx->track_impl != 1 && epl <= 16 && fpl <= 16 && wlds <= 48 * 1024) {  // feature per wave
+    if (!stage) {
+      if (epl <= 1) GKLT_TRACK_W(1, 0);
+      else if (epl <= 2) GKLT_TRACK_W(2, 0);
+      else if (epl <= 4) GKLT_TRACK_W(4, 0);
+      else if (epl <= 8) GKLT_TRACK_W(8, 0);
+      else GKLT_TRACK_W(16, 0);
+    } else if (epl <= 1) {
+      if (fpl <= 1) GKLT_TRACK_W(1, 1); else GKLT_TRACK_W(1, 2);
+    } else if (epl <= 2) {
+      if (fpl <= 2) GKLT_TRACK_W(2, 2); else GKLT_TRACK_W(2, 4);
+    } else if (epl <= 4) {
+      if (fpl <= 4) GKLT_TRACK_W(4, 4); else GKLT_TRACK_W(4, 8);
+    } else if (epl <= 8) {
+      if (fpl <= 8) GKLT_TRACK_W(8, 8); else GKLT_TRACK_W(8, 16);
+    } else {
+      GKLT_TRACK_W(16, 16);
+    }
 #undef GKLT_TRACK_W
   } else if (a.ww == 7 && a.wh == 7) {
     hipLaunchKernelGGL((k_track<7, 7>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);

@@ -216,8 +216,9 @@ int gklt_device_synchronize(gklt_ctx *ctx);
 
 /* ---- measurement ---- */
 
-/* Tracker mapping: 0 = one feature per wavefront (default), 1 = one feature per 8-lane slice.
- * Both produce identical results; kept selectable for A/B timing. */
+/* Tracker mapping: 0 = one feature per wavefront, LDS footprint staging chosen by window size
+ * (default); 1 = one feature per 8-lane slice; 2 / 3 = per wavefront without / with staging.
+ * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
 
 

@@ -63,15 +63,17 @@ def test_track_exact(klt, ok, gpu_ctx, window, levels, H, W, n):
     assert (got[2] == 0).mean() > 0.9  # the synthetic pan is well inside the capture range
 
 
+@pytest.mark.parametrize("impl", [1, 2, 3])
 @pytest.mark.parametrize("window,levels", [(7, 4), (11, 3), (21, 2), (5, 3)])
-def test_track_slice_kernels_agree(klt, ok, gpu_ctx, window, levels):
-    """The alternative mapping (one feature per 8-lane slice) gives the same bits."""
+def test_track_alternative_kernels_agree(klt, ok, gpu_ctx, window, levels, impl):
+    """The alternative mappings (1: one feature per 8-lane slice; 2: one feature per wavefront
+    without the LDS footprint) give the same bits as the default kernel and the oracle."""
     H, W, n = 270, 480, 500
     f = _stream(H, W, 2)
     p = ok.make_params(window=window, levels=levels)
     x, y = synth.lattice_seeds(H, W, n, p.borderx)
     val = np.zeros(len(x), np.int32)
-    gpu_ctx.set_track_impl(1)
+    gpu_ctx.set_track_impl(impl)
     try:
         got, ref = _run_pair(klt, ok, gpu_ctx, f[0], f[1], window, levels, x, y, val)
     finally:
