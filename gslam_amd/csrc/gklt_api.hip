@@ -285,6 +285,36 @@ int gklt::enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const ui
   half_taps(g, gw, +1, &gradg);
   half_taps(d, dw, -1, &gradd);
 
+  // One fused launch per level when the radii are the instantiated ones (the reference's
+  // defaults); level l+1 must be an exact 2x decimation for the fused down-sampling.
+  const bool fuse = ctx->pyr_impl != 1 &&
+                    level_fusable(&smooth0, py->nlevels > 1 ? &pyr : nullptr, gradg, gradd);
+  if (fuse) {
+    for (int l = 0; l < py->nlevels; ++l) {
+      const Level &a = py->lv[l];
+      const bool last = l + 1 == py->nlevels;
+      const bool exact = !last && a.w == 2 * py->lv[l + 1].w && a.h == 2 * py->lv[l + 1].h;
+      float *down = exact ? py->lv[l + 1].img : nullptr;
+      const int w2 = exact ? py->lv[l + 1].w : 0, h2 = exact ? py->lv[l + 1].h : 0;
+      if (l == 0) {
+        // the planar level-0 image is only materialised when the generic resize below needs it
+        float *img0 = (!last && !exact) ? a.img : nullptr;
+        if (int rc = launch_level_u8(ctx, s, src, src_stride, a, smooth0, exact ? &pyr : nullptr,
+                                     gradg, gradd, img0, down, w2, h2))
+          return rc;
+      } else {
+        if (int rc = launch_level_f32(ctx, s, a, exact ? &pyr : nullptr, gradg, gradd, down, w2, h2))
+          return rc;
+      }
+      if (!last && !exact) {
+        const Level &b = py->lv[l + 1];
+        if (int rc = launch_smooth_f32(ctx, s, a.img, a.w, a.h, pyr, py->tmp, GKLT_K_DOWN)) return rc;
+        if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
+      }
+    }
+    return 0;
+  }
+
   // pyramid.cpp:59-61  u8 -> f32 -> smooth
   if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, smooth0, py->lv[0].img)) return rc;
   for (int l = 1; l < py->nlevels; ++l) {  // pyramid.cpp:62-66
@@ -308,12 +338,10 @@ extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level,
   if (dst_stride < L.w) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   hipStream_t s = ctx->s_pyr;
-  const float *src = L.img;
-  if (plane != 0) {
-    GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
-    if (int rc = launch_tex_extract(ctx, s, L.tex, L.w * L.h, plane, py->tmp)) return rc;
-    src = py->tmp;
-  }
+  // every plane comes out of the texels: the fused build never writes level 0's planar image
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  if (int rc = launch_tex_extract(ctx, s, L.tex, L.w * L.h, plane, py->tmp)) return rc;
+  const float *src = py->tmp;
   GKLT_HIP(hipMemcpy2DAsync(dst, sizeof(float) * dst_stride, src, sizeof(float) * L.w,
                             sizeof(float) * L.w, L.h, hipMemcpyDeviceToHost, s));
   GKLT_HIP(hipStreamSynchronize(s));
@@ -621,5 +649,12 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
 extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->track_impl = impl;
+  return 0;
+}
+
+// 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels
+extern "C" int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl) {
+  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  ctx->pyr_impl = impl;
   return 0;
 }

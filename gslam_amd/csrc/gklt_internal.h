@@ -63,6 +63,7 @@ struct gklt_ctx {
   double *d_norm = nullptr, *d_vec = nullptr;
   int d_nv_capacity = 0;
   // profiling
+  int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;
   struct Span {
@@ -123,6 +124,13 @@ int launch_gradients_tex(gklt_ctx *ctx, hipStream_t s, const Level *levels, int 
                          const Taps &g, const Taps &d);
 int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int w, int h,
                             const Taps &g, const Taps &d, float *gx, float *gy);
+// fused level kernels (one launch per level): see gklt_pyramid.hip
+bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d);
+int launch_level_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, const Level &L,
+                    const Taps &s0, const Taps *pyr, const Taps &g, const Taps &d, float *img_out,
+                    float *down, int w2, int h2);
+int launch_level_f32(gklt_ctx *ctx, hipStream_t s, const Level &L, const Taps *pyr, const Taps &g,
+                     const Taps &d, float *down, int w2, int h2);
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);
 int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp, const float *src);
 

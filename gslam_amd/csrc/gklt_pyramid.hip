@@ -429,6 +429,203 @@ constexpr size_t fast_grad_lds() {
   return sizeof(float) * (size_t)(FastGeom<R>::IH * FastGeom<R>::IWP + 2 * FastGeom<R>::IH * TW);
 }
 
+// ---------------------------------------------------------------- fused level kernel -------
+// One launch per pyramid level does everything that level needs:
+//   level 0 : u8 tile -> smooth(sigma0) -> I (in LDS only)        (pyramid.cpp:59-61)
+//   level l : planar I_l tile -> I (in LDS)
+//   then    : gradients of I -> texels (I, gx, gy, 0)             (pyramid.cpp:72-83)
+//             smooth(sigma_pyr) of I -> 2x2 mean -> planar I_{l+1} (pyramid.cpp:62-66)
+// so a level's image is read from HBM once, level 0's fp32 plane is never written, and a build is
+// nlevels launches.  I is produced with a halo of HI = max(RP, RG) pixels around the tile; at
+// level 0 the halo pixels are smoothed from the reflected u8 window, which gives the same bits
+// as reflecting the smoothed plane because the taps are symmetric and each pair sum
+// (s[+j] + s[-j]) is commutative.  All passes are the register-blocked ones described above.
+template <int R0, int HI>
+struct LevelGeom {
+  static constexpr int HIP = (HI + 3) / 4 * 4;    // halo of I padded to whole float4 groups
+  static constexpr int AW = TW + 2 * HIP;         // row length of A and I
+  static constexpr int IHh = TH + 2 * HI;         // rows of I
+  static constexpr int R0P = (R0 + 3) / 4 * 4;
+  static constexpr int SW = AW + 2 * R0P;         // staged source row length (R0 > 0)
+  static constexpr int SH = IHh + 2 * R0;         // staged source rows       (R0 > 0)
+  static constexpr int OA = R0P - R0;             // first needed float of a level-0 row window
+  static constexpr int NGA = (OA + 3 + 2 * R0) / 4 + 1;
+  static constexpr int OI = HIP - HI;             // first needed float of an I row window
+  static constexpr int NGI = (OI + 3 + 2 * HI) / 4 + 1;
+  static constexpr int STRIPS = NT / AW;          // column pass of level 0: strips per column
+  static constexpr int SR = (IHh + STRIPS - 1) / STRIPS;
+  static_assert(SW <= 128 && AW % 4 == 0, "two lane chunks per staged row");
+  static_assert(4 * NGA - 4 <= 2 * R0P && 60 + 4 * NGI <= AW, "row windows stay inside a row");
+};
+
+// out[ROWS][WIDTH] <- src[reflect(ys + ty)][reflect(xs + tx)], every load issued before the
+// first LDS store.
+template <int ROWS, int WIDTH, typename SrcT>
+__device__ __forceinline__ void stage_region(const SrcT *__restrict__ src, int stride, int w, int h,
+                                             int xs, int ys, float *out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int PER = (ROWS + NW - 1) / NW;
+  const int sx0 = reflect101(xs + lane, w);
+  const int sx1 = reflect101(xs + 64 + min(lane, WIDTH - 65), w);
+  SrcT v0[PER], v1[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ty = wave + i * NW;
+    const int sy = reflect101(ys + min(ty, ROWS - 1), h);
+    const SrcT *row = src + (size_t)sy * stride;
+    v0[i] = row[sx0];
+    v1[i] = row[sx1];
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int ty = wave + i * NW;
+    if (ty < ROWS) {
+      out[ty * WIDTH + lane] = static_cast<float>(v0[i]);
+      if (lane < WIDTH - 64) out[ty * WIDTH + 64 + lane] = static_cast<float>(v1[i]);
+    }
+  }
+}
+
+template <int NG>
+__device__ __forceinline__ void load_groups(const float *p, float (&v)[4 * NG]) {
+  const float4 *q4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    const float4 f = q4[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+}
+
+template <typename SrcT, int R0, int RP, int RG, bool DOWN>
+__global__ __launch_bounds__(NT) void k_level(const SrcT *__restrict__ src, int stride, int w,
+                                              int h, Taps s0, Taps pyr, Taps g, Taps d,
+                                              Texel *__restrict__ tex, float *__restrict__ img_out,
+                                              float *__restrict__ down, int w2, int h2) {
+  constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
+  using G = LevelGeom<R0, HI>;
+  constexpr int GH = TH + 2 * RG;  // rows of the gradient row pass
+  constexpr int GOFF = HI - RG;    // its first row inside I
+  extern __shared__ __align__(16) float lds[];
+  float *I = lds;                        // IHh x AW
+  float *scratch = I + G::IHh * G::AW;   // level-0 phase: S, A; afterwards: rowd, rowg, rowp
+  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  if constexpr (R0 > 0) {
+    float *S = scratch;               // SH x SW source window
+    float *A = S + G::SH * G::SW;     // SH x AW rows smoothed
+    stage_region<G::SH, G::SW>(src, stride, w, h, x0 - G::HIP - G::R0P, y0 - HI - R0, S);
+    __syncthreads();
+    constexpr int GPR = G::AW / 4;
+#pragma unroll
+    for (int task = threadIdx.x; task < G::SH * GPR; task += NT) {
+      const int ty = task / GPR, gq = task - ty * GPR;
+      float v[4 * G::NGA];
+      load_groups<G::NGA>(S + ty * G::SW + 4 * gq, v);
+      float4 o;
+      o.x = corr_win<R0, +1>(v, G::OA + R0 + 0, s0);
+      o.y = corr_win<R0, +1>(v, G::OA + R0 + 1, s0);
+      o.z = corr_win<R0, +1>(v, G::OA + R0 + 2, s0);
+      o.w = corr_win<R0, +1>(v, G::OA + R0 + 3, s0);
+      *reinterpret_cast<float4 *>(A + ty * G::AW + 4 * gq) = o;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G::STRIPS * G::AW) {
+      const int strip = threadIdx.x / G::AW, col = threadIdx.x - strip * G::AW;
+      float v[G::SR + 2 * R0];
+#pragma unroll
+      for (int i = 0; i < G::SR + 2 * R0; ++i)
+        v[i] = A[min(strip * G::SR + i, G::SH - 1) * G::AW + col];
+#pragma unroll
+      for (int j = 0; j < G::SR; ++j) {
+        const int rr = strip * G::SR + j;
+        const float o = corr_win<R0, +1>(v, R0 + j, s0);
+        if (rr < G::IHh) I[rr * G::AW + col] = o;
+      }
+    }
+    __syncthreads();
+  } else {
+    stage_region<G::IHh, G::AW>(src, stride, w, h, x0 - G::HIP, y0 - HI, I);
+    __syncthreads();
+  }
+
+  float *rowd = scratch;            // GH x TW  : rows filtered with G'
+  float *rowg = rowd + GH * TW;     // GH x TW  : rows filtered with G
+  float *rowp = rowg + GH * TW;     // IHh x TW : rows filtered with the pyramid kernel (DOWN)
+#pragma unroll
+  for (int task = threadIdx.x; task < G::IHh * (TW / 4); task += NT) {
+    const int ty = task >> 4, gq = task & 15;
+    float v[4 * G::NGI];
+    load_groups<G::NGI>(I + ty * G::AW + 4 * gq, v);
+    constexpr int C = G::OI + HI;
+    if constexpr (DOWN) {
+      float4 op;
+      op.x = corr_win<RP, +1>(v, C + 0, pyr);
+      op.y = corr_win<RP, +1>(v, C + 1, pyr);
+      op.z = corr_win<RP, +1>(v, C + 2, pyr);
+      op.w = corr_win<RP, +1>(v, C + 3, pyr);
+      *reinterpret_cast<float4 *>(rowp + ty * TW + 4 * gq) = op;
+    }
+    const int tg = ty - GOFF;
+    if (tg >= 0 && tg < GH) {
+      float4 od, og;
+      od.x = corr_win<RG, -1>(v, C + 0, d); og.x = corr_win<RG, +1>(v, C + 0, g);
+      od.y = corr_win<RG, -1>(v, C + 1, d); og.y = corr_win<RG, +1>(v, C + 1, g);
+      od.z = corr_win<RG, -1>(v, C + 2, d); og.z = corr_win<RG, +1>(v, C + 2, g);
+      od.w = corr_win<RG, -1>(v, C + 3, d); og.w = corr_win<RG, +1>(v, C + 3, g);
+      *reinterpret_cast<float4 *>(rowd + tg * TW + 4 * gq) = od;
+      *reinterpret_cast<float4 *>(rowg + tg * TW + 4 * gq) = og;
+    }
+  }
+  __syncthreads();
+
+  {  // gradient column pass -> texels
+    float vd[4 + 2 * RG], vg[4 + 2 * RG];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * RG; ++i) {
+      vd[i] = rowd[(4 * wave + i) * TW + lane];
+      vg[i] = rowg[(4 * wave + i) * TW + lane];
+    }
+    const int x = x0 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = y0 + 4 * wave + j;
+      const float gx = corr_win<RG, +1>(vd, RG + j, g);
+      const float gy = corr_win<RG, -1>(vg, RG + j, d);
+      const float ic = I[(4 * wave + j + HI) * G::AW + G::HIP + lane];
+      if (x < w && y < h) {
+        tex[(size_t)y * w + x] = make_float4(ic, gx, gy, 0.0f);
+        if (img_out) img_out[(size_t)y * w + x] = ic;
+      }
+    }
+  }
+  if constexpr (DOWN) {  // pyramid column pass -> 2x2 mean -> next level
+    float v[4 + 2 * RP], o[4];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * RP; ++i) v[i] = rowp[(4 * wave + i + HI - RP) * TW + lane];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = corr_win<RP, +1>(v, RP + j, pyr);
+    const int x = x0 / 2 + (lane >> 1);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const float a = o[2 * jj], c = o[2 * jj + 1];
+      const float b = __shfl_xor(a, 1), e = __shfl_xor(c, 1);
+      const float m = (((a + b) + c) + e) * 0.25f;
+      const int y = y0 / 2 + 2 * wave + jj;
+      if (!(lane & 1) && x < w2 && y < h2) down[(size_t)y * w2 + x] = m;
+    }
+  }
+}
+
+template <int R0, int RP, int RG, bool DOWN>
+constexpr size_t level_lds() {
+  constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
+  using G = LevelGeom<R0, HI>;
+  constexpr size_t p1 = R0 > 0 ? (size_t)G::SH * (G::SW + G::AW) : 0;
+  constexpr size_t p2 = 2 * (size_t)(TH + 2 * RG) * TW + (DOWN ? (size_t)G::IHh * TW : 0);
+  return sizeof(float) * ((size_t)G::IHh * G::AW + (p1 > p2 ? p1 : p2));
+}
+
 // ---------------------------------------------------------------- generic resize -----------
 // cv::resize(INTER_LINEAR) for scales other than exactly 2 (pyramid.cpp:65 with subsampling 4/8
 // or odd sizes): sx = (dx+0.5)*(W/W2)-0.5, source index clamped, horizontal then vertical blend.
@@ -547,7 +744,60 @@ int launch_grad_batch(gklt_ctx *ctx, hipStream_t s, GradBatch &b, const Taps &g,
   return 0;
 }
 
+template <typename SrcT, int R0, bool DOWN>
+int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const SrcT *src, int stride,
+                      const Level &L, const Taps &s0, const Taps &pyr, const Taps &g, const Taps &d,
+                      float *img_out, float *down, int w2, int h2) {
+  auto kern = k_level<SrcT, R0, 5, 3, DOWN>;
+  constexpr size_t lds = level_lds<R0, 5, 3, DOWN>();
+  static_assert(lds <= 48 * 1024, "fused level kernel fits the default LDS limit");
+  ProfScope ps(ctx, s, prof_id);
+  hipLaunchKernelGGL(kern, tile_grid(L.w, L.h), dim3(NT), lds, s, src, stride, L.w, L.h, s0, pyr, g,
+                     d, L.tex, img_out, down, w2, h2);
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace
+
+// Radii the fused level kernel is instantiated for: grad_sigma = 1.0 (R 3), pyramid sigma 1.8
+// (subsampling 2 * 0.9, R 5), level-0 smoothing radius 1..4 (windows up to 19 px).
+bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d) {
+  if (g.r != 3 || d.r != 3) return false;
+  if (pyr && pyr->r != 5) return false;
+  if (s0 && (s0->r < 1 || s0->r > 4)) return false;
+  return true;
+}
+
+int launch_level_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, const Level &L,
+                    const Taps &s0, const Taps *pyr, const Taps &g, const Taps &d, float *img_out,
+                    float *down, int w2, int h2) {
+  const Taps &p = pyr ? *pyr : g;
+#define GKLT_LEVEL_CASE(RR)                                                                       \
+  case RR:                                                                                        \
+    return down ? launch_level_inst<uint8_t, RR, true>(ctx, s, GKLT_K_LEVEL0, src, stride, L, s0, \
+                                                       p, g, d, img_out, down, w2, h2)            \
+                : launch_level_inst<uint8_t, RR, false>(ctx, s, GKLT_K_LEVEL0, src, stride, L,    \
+                                                        s0, p, g, d, img_out, nullptr, 0, 0);
+  switch (s0.r) {
+    GKLT_LEVEL_CASE(1)
+    GKLT_LEVEL_CASE(2)
+    GKLT_LEVEL_CASE(3)
+    GKLT_LEVEL_CASE(4)
+  }
+#undef GKLT_LEVEL_CASE
+  set_error("fused level kernel: unsupported level-0 radius %d", s0.r);
+  return GKLT_EINVAL;
+}
+
+int launch_level_f32(gklt_ctx *ctx, hipStream_t s, const Level &L, const Taps *pyr, const Taps &g,
+                     const Taps &d, float *down, int w2, int h2) {
+  const Taps &p = pyr ? *pyr : g;
+  return down ? launch_level_inst<float, 0, true>(ctx, s, GKLT_K_LEVELN, L.img, L.w, L, g, p, g, d,
+                                                  nullptr, down, w2, h2)
+              : launch_level_inst<float, 0, false>(ctx, s, GKLT_K_LEVELN, L.img, L.w, L, g, p, g, d,
+                                                   nullptr, nullptr, 0, 0);
+}
 
 int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,
                      const Taps &g, float *dst) {

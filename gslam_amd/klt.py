@@ -15,8 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libgklt.so")
 
 KLT_TRACKED, KLT_NOT_FOUND, KLT_SMALL_DET = 0, -1, -2
 KLT_MAX_ITERATIONS, KLT_OOB, KLT_LARGE_RESIDUE = -3, -4, -5
-K_SMOOTH0, K_DOWN, K_GRAD, K_TRACK, K_MISC = range(5)
-KERNEL_NAMES = {K_SMOOTH0: "smooth0", K_DOWN: "down", K_GRAD: "grad", K_TRACK: "track", K_MISC: "misc"}
+K_SMOOTH0, K_DOWN, K_GRAD, K_TRACK, K_MISC, K_INTEGRAL, K_SELECT, K_LEVEL0, K_LEVELN = range(9)
+KERNEL_NAMES = {K_SMOOTH0: "smooth0", K_DOWN: "down", K_GRAD: "grad", K_TRACK: "track", K_MISC: "misc",
+                K_INTEGRAL: "integral", K_SELECT: "select", K_LEVEL0: "level0", K_LEVELN: "leveln"}
 
 
 class GkltError(RuntimeError):
@@ -157,6 +158,10 @@ class Context:
     def set_track_impl(self, impl):
         """0 = one feature per wavefront (default), 1 = one feature per 8-lane slice."""
         _check(lib().gklt_ctx_set_track_impl(self.h, int(impl)))
+
+    def set_pyramid_impl(self, impl):
+        """0 = fused level kernels when the radii allow (default), 1 = separate kernels."""
+        _check(lib().gklt_ctx_set_pyramid_impl(self.h, int(impl)))
 
     def close(self):
         if self.h:

@@ -220,6 +220,10 @@ int gklt_device_synchronize(gklt_ctx *ctx);
  * (default); 1 = one feature per 8-lane slice; 2 / 3 = per wavefront without / with staging.
  * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
+/* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level) when the
+ * kernel radii are the reference's defaults, separate kernels otherwise (default); 1 = always
+ * the separate smooth / decimate / gradient kernels.  Identical results. */
+int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
 
 
 enum {
@@ -230,7 +234,9 @@ enum {
   GKLT_K_MISC = 4,
   GKLT_K_INTEGRAL = 5, /* products + integral images */
   GKLT_K_SELECT = 6,   /* score, suppression rounds, rank/assign */
-  GKLT_K_COUNT = 7
+  GKLT_K_LEVEL0 = 7,   /* fused level 0: u8 -> smooth -> texels + level 1 */
+  GKLT_K_LEVELN = 8,   /* fused level l > 0: I_l -> texels + level l+1 */
+  GKLT_K_COUNT = 9
 };
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream. */
 int gklt_profile_enable(gklt_ctx *ctx, int on);

@@ -34,19 +34,27 @@ def _assert_bits(a, b, what):
     (37, 53, 5, 2),        # ragged, smaller than a tile
     (16, 64, 3, 1),        # single level, exactly one tile
     (200, 333, 9, 3),
+    (64, 128, 15, 3),      # level-0 radius 3/4
+    (48, 96, 19, 2),
+    (9, 11, 3, 1),         # smaller than every halo: repeated reflection
+    (20, 24, 7, 2),
+    (130, 258, 7, 3),      # one pixel past a tile edge in both directions
 ])
-def test_pyramid_bit_exact(klt, ok, gpu_ctx, H, W, window, levels):
+@pytest.mark.parametrize("impl", [0, 1])   # fused level kernels / separate kernels
+def test_pyramid_bit_exact(klt, ok, gpu_ctx, H, W, window, levels, impl):
     img = _frame(H, W)
     gp = klt.make_params(window=window, levels=levels)
     op = ok.make_params(window=window, levels=levels)
     assert gp.borderx == op.borderx
     gpu_ctx.set_params(gp)
+    gpu_ctx.set_pyramid_impl(impl)
     pyr = klt.Pyramid(gpu_ctx, W, H)
     try:
         pyr.build(img)
         got = pyr.planes()
     finally:
         pyr.close()
+        gpu_ctx.set_pyramid_impl(0)
     ref = ok.compute_pyramid(op, img)
     assert len(got) == len(ref) == 3 * levels
     for i, (a, b) in enumerate(zip(got, ref)):
