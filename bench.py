@@ -2,9 +2,14 @@
 """bench.py -- BASELINE.json metric: tracked features * frames / s on the synthetic 1080p stream
 (config C2: 4000 features, 4-level pyramid, 7x7 window), one independent stream per GPU.
 
-A step = one frame of one stream through gklt_pipeline_step: build pyramid(t+1) while tracking
-(t-1 -> t), the tracker writing the frame's feature list into pinned host memory (the overlap of
-System.cpp:501-518).  Frames are resident in HBM before the timed region.
+A step = one frame of one stream: its pyramid is built and the feature list is tracked from the
+previous frame to it, the tracker writing the frame's list into pinned host memory.  Frames are
+resident in HBM before the timed region.  The timed leg hands the frames to gklt_lookahead in
+batches of --lookahead frames (pyramids of a batch: one launch per level; tracking of a batch: one
+launch; build(batch k) overlaps track(batch k-1) -- the overlap of System.cpp:501-518 with a
+deeper preload).  --lookahead 0 times gklt_pipeline_step instead (one frame per call, the
+reference's preload depth of one); that mode is also what the latency leg and the
+"frame_at_a_time" block report.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|Cship]
 N > 1 is launched by torch.distributed.run, one rank per GPU.  Streams are independent, so
@@ -31,6 +36,9 @@ klt.lib()  # load libgklt.so (and the system HIP runtime) before anything can im
 
 RESEED_EVERY = 32
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per single-frame launch measured with rocprofv3 --pmc (TCC_EA0_RDREQ*/WRREQ* passes,
+# profiles/r01_c2_pmc_by_kernel.txt); None where no PMC pass has been committed.
+PMC_TRAFFIC = {("C2", "track"): 21.6e6 + 1.0e6}
 
 
 def parse():
@@ -40,6 +48,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--config", default="C2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--frames", type=int, default=64, help="distinct synthetic frames (looped)")
+    ap.add_argument("--lookahead", type=int, default=16,
+                    help="frames per gklt_lookahead_submit (0 = gklt_pipeline_step, frame at a time)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -67,20 +77,85 @@ class Stream:
         self.pipe.upload_features(*self.seeds)
         self.pipe.start(self.frame(0), self.frame(1))
         self.t = 1
+        self.next_reseed = 1 + RESEED_EVERY
 
     def step(self):
         """pyramid(t+1) || track(t-1 -> t) -> async D2H of the list."""
         t = self.t
-        if t % RESEED_EVERY == 0:  # keep the tracked fraction constant (SURVEY 8d)
+        if t >= self.next_reseed:  # keep the tracked fraction constant (SURVEY 8d)
             self.pipe.upload_features(*self.seeds)
+            self.next_reseed += RESEED_EVERY
         self.pipe.step(self.frame(t + 1), self.host[t % 4][1])
         self.t = t + 1
+
+    def run(self, nframes):
+        for _ in range(nframes):
+            self.step()
 
     def sync(self):
         self.pipe.sync()
 
     def close(self):
         self.pipe.close()
+        for p in self.ptrs:
+            self.ctx.device_free(p)
+        for _, p in self.host:
+            self.ctx.pinned_free(p)
+
+
+class LookaheadStream:
+    """The same stream through gklt_lookahead: batches of B frames per call."""
+
+    def __init__(self, ctx, cfg, frames, seeds, B):
+        assert RESEED_EVERY % B == 0
+        self.ctx, self.cfg, self.B = ctx, cfg, B
+        H, W, n = cfg["H"], cfg["W"], cfg["n"]
+        self.la = klt.Lookahead(ctx, W, H, n, B)
+        self.fl = self.la.flist
+        self.ptrs = [ctx.device_upload(f) for f in frames]
+        self.seeds = seeds
+        self.t = 1           # next frame to submit
+        self.pending = None  # first frame of the batch that the next submit will track
+        self.host = [ctx.pinned_array((3, n), np.float32) for _ in range(4 * B)]
+
+    def frame(self, t):
+        return (self.ptrs[t % len(self.ptrs)], self.cfg["W"])
+
+    def start(self):
+        self.la.upload_features(*self.seeds)
+        self.la.start(self.frame(0))
+        self.t, self.pending = 1, None
+        self.next_reseed = 1 + RESEED_EVERY
+
+    def _reseed_if_due(self):
+        # the next tracker launch starts at frame self.pending: same rule as Stream.step (a
+        # re-seed can only fall on the first frame of a batch; B divides RESEED_EVERY)
+        t = self.pending
+        if t is not None and t >= self.next_reseed:
+            self.la.upload_features(*self.seeds)
+            self.next_reseed += RESEED_EVERY
+
+    def run(self, nframes):
+        """submits nframes frames in batches of B (last one ragged)"""
+        done = 0
+        while done < nframes:
+            b = min(self.B, nframes - done)
+            t = self.t
+            self._reseed_if_due()
+            self.la.submit([self.frame(k) for k in range(t, t + b)],
+                           [self.host[k % len(self.host)][1] for k in range(t, t + b)])
+            self.pending = t
+            self.t = t + b
+            done += b
+
+    def sync(self):
+        """tracks the pending batch and waits"""
+        self._reseed_if_due()
+        self.la.flush()
+        self.pending = None
+
+    def close(self):
+        self.la.close()
         for p in self.ptrs:
             self.ctx.device_free(p)
         for _, p in self.host:
@@ -164,10 +239,13 @@ def main():
     sx, sy = synth.lattice_seeds(H, W, n, gp.borderx, seed=seed, nx=cfg["lattice"][0], ny=cfg["lattice"][1])
     seeds = (sx, sy, np.zeros(len(sx), np.int32))
 
-    st = Stream(ctx, cfg, frames, seeds)
+    B = a.lookahead
+    if B:
+        st = LookaheadStream(ctx, cfg, frames, seeds, B)
+    else:
+        st = Stream(ctx, cfg, frames, seeds)
     st.start()
-    for _ in range(a.warmup):
-        st.step()
+    st.run(a.warmup)
     st.sync()
     st.fl.stats(reset=True)
 
@@ -178,8 +256,7 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        st.step()
+    st.run(a.steps)
     st.sync()
     ctx.device_synchronize()
     dt = time.perf_counter() - t0
@@ -191,33 +268,57 @@ def main():
     psteps = min(a.steps, 512)
     ctx.profile_enable(True)
     ctx.profile_reset()
-    for _ in range(psteps):
-        st.step()
+    st.run(psteps)
     st.sync()
     prof = ctx.profile_get()
     ctx.profile_enable(False)
     p_tracked, p_iters = st.fl.stats(reset=True)
 
-    # ---- per-frame latency, synchronous use (what System::Track sees)
+    # ---- frame at a time (gklt_pipeline_step): throughput, and synchronous per-frame latency
+    # (what System::Track sees)
+    if B:
+        st.close()
+        st1 = Stream(ctx, cfg, frames, seeds)
+        st1.start()
+        st1.run(a.warmup)
+        st1.sync()
+        st1.fl.stats(reset=True)
+        k1 = min(a.steps, 1024)
+        q0 = time.perf_counter()
+        st1.run(k1)
+        st1.sync()
+        dt1 = time.perf_counter() - q0
+        tracked1, _ = st1.fl.stats(reset=True)
+    else:
+        st1, k1, dt1, tracked1 = st, a.steps, dt, tracked
     lat = []
     for _ in range(min(a.steps, 256)):
         q0 = time.perf_counter()
-        st.step()
-        st.sync()
+        st1.step()
+        st1.sync()
         lat.append((time.perf_counter() - q0) * 1e3)
     lat = np.array(lat)
 
     b_pyr, foot, px = algorithmic_bytes(cfg)
     per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}
                   for k, (ms, cnt) in prof.items() if cnt}
-    dom = "track"  # the largest single launch of the pipeline (rocprofv3 summary in profiles/)
+    fpl = max(B, 1)  # frames per launch
+    # Algorithmic bytes per launch.  Tracker: n features x L levels x (3 template
+    # planes + 1 residue plane) + 3 planes per Newton iteration, each plane one (w+1)(h+1) fp32
+    # bilinear footprint.  Level-0 kernel: u8 in, (I, gx, gy) out, decimated plane out.
+    alg_by_kernel = {
+        "track": (4.0 * n * cfg["levels"] * fpl + 3.0 * p_iters / psteps * fpl) * foot,
+        "level0": fpl * W * H * (1 + 12 + 1.0),
+    }
+    dom = max((k for k in per_kernel if k in alg_by_kernel), key=lambda k: per_kernel[k]["total_ms"])
     avg_s = per_kernel[dom]["avg_us"] * 1e-6
-    # per launch: n features x L levels x (3 template planes + 1 residue plane) + 3 planes per
-    # Newton iteration, each plane one (w+1)(h+1) fp32 bilinear footprint  
-    passes = 4.0 * n * cfg["levels"] + 3.0 * p_iters / psteps
-    alg = passes * foot
+    alg = alg_by_kernel[dom]
     achieved = alg / avg_s / 1e9
+    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (TCC_EA0 read +
+    # write requests, gfx950 units as in MI355X_MICROARCH.md); measured at one frame per launch.
+    pmc_traffic = PMC_TRAFFIC.get((a.config, dom))
 
+    names = {"track": "k_track_w", "level0": "k_level<u8>"}
     out = {
         "metric": "tracked features*frames/sec at 1080p, 4000 pts, 4-level pyramid; per-frame latency",
         "value": tracked_all / dt_max,
@@ -237,16 +338,26 @@ def main():
                    "frames_per_s": world * a.steps / dt_max,
                    "tracked_fraction": tracked_all / (world * a.steps * n),
                    "newton_iters_per_feature_frame": iters_all / (world * a.steps * n),
-                   "launch": "eager, 2 alternating streams, 1 event wait/frame",
+                   "lookahead_frames": B,
+                   "launch": ("gklt_lookahead: %d frames per call, one launch per pyramid level and one "
+                              "tracker launch per batch, build(k) || track(k-1)" % B) if B else
+                             "gklt_pipeline_step: eager, 2 alternating streams, 1 event wait/frame",
                    "parallelism": "stream-sharded x%d, no collective" % world},
+        "frame_at_a_time": {"value": tracked1 / dt1, "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
+                            "mode": "gklt_pipeline_step (preload depth 1, as System.cpp:501-518), rank 0"},
         "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                       "mode": "synchronous step: pyramid(t+1) || track(t-1->t) + D2H of the list"},
-        "roofline": {"bound": "hbm", "kernel": "k_track", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                       "mode": "synchronous gklt_pipeline_step: pyramid(t+1) || track(t-1->t) + list "
+                               "in pinned host memory"},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": pmc_traffic * fpl if pmc_traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": per_kernel[dom]["avg_us"],
-                     "note": "tracker gather bytes [4*N*L + 3*iters] footprints of (w+1)(h+1)*4 B; "
-                             "iters/feature/frame=%.2f; latency-bound gathers served by L2/MALL, "
-                             "see DESIGN.md 4.3" % (p_iters / psteps / n)},
+                     "frames_per_launch": fpl,
+                     "note": "dominant kernel by total time in the profiled leg; tracker bytes = "
+                             "[4*N*L + 3*iters] footprints of (w+1)(h+1)*4 B per frame "
+                             "(iters/feature/frame=%.2f), level-0 bytes = W*H*(1+12+1) per frame; "
+                             "traffic = PMC bytes/launch from profiles/ (separate rocprofv3 --pmc "
+                             "passes) scaled by frames_per_launch; see DESIGN.md 4" % (p_iters / psteps / n)},
         "kernels": per_kernel,
         "pyramid_algorithmic_bytes_per_frame": b_pyr,
     }
@@ -259,7 +370,7 @@ def main():
                                "kind": "port",
                                "sample": "%d frames of the same stream (pyramid + track), oracle/ C "
                                          "restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
-    st.close()
+    st1.close()
     ctx.close()
     if rank == 0:
         print(json.dumps(out))

@@ -268,66 +268,97 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
 // runtime, three kernel launches' worth: tools/hip_overheads.cpp).
 int gklt::enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
                         int src_stride) {
-  const gklt_params &P = ctx->prm;
-  const int W = py->lv[0].w, H = py->lv[0].h;
-  // kernels for this call: the reference recomputes them on every call
+  return enqueue_build_batch(ctx, s, &py, &src, 1, src_stride);
+}
+
+namespace {
+struct BuildTaps {
+  gklt::Taps smooth0, pyr, gradg, gradd;
+};
+
+// kernels for this call: the reference recomputes them on every call
+int build_taps(const gklt_params &P, int nlevels, BuildTaps *t) {
   float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
   int gw, dw;
-  Taps smooth0, pyr, gradg, gradd;
   if (int rc = gklt_compute_kernels(gklt_compute_smooth_sigma(&P), g, &gw, d, &dw)) return rc;
-  half_taps(g, gw, +1, &smooth0);
-  if (py->nlevels > 1) {
+  gklt::half_taps(g, gw, +1, &t->smooth0);
+  if (nlevels > 1) {
     if (int rc = gklt_compute_kernels(P.subsampling * P.pyramid_sigma_fact, g, &gw, d, &dw))
       return rc;  // pyramid.cpp:56
-    half_taps(g, gw, +1, &pyr);
+    gklt::half_taps(g, gw, +1, &t->pyr);
   }
   if (int rc = gklt_compute_kernels(P.grad_sigma, g, &gw, d, &dw)) return rc;  // pyramid.cpp:69-71
-  half_taps(g, gw, +1, &gradg);
-  half_taps(d, dw, -1, &gradd);
+  gklt::half_taps(g, gw, +1, &t->gradg);
+  gklt::half_taps(d, dw, -1, &t->gradd);
+  return 0;
+}
 
-  // One fused launch per level when the radii are the instantiated ones (the reference's
-  // defaults); level l+1 must be an exact 2x decimation for the fused down-sampling.
-  const bool fuse = ctx->pyr_impl != 1 &&
-                    level_fusable(&smooth0, py->nlevels > 1 ? &pyr : nullptr, gradg, gradd);
-  if (fuse) {
-    for (int l = 0; l < py->nlevels; ++l) {
-      const Level &a = py->lv[l];
-      const bool last = l + 1 == py->nlevels;
-      const bool exact = !last && a.w == 2 * py->lv[l + 1].w && a.h == 2 * py->lv[l + 1].h;
-      float *down = exact ? py->lv[l + 1].img : nullptr;
-      const int w2 = exact ? py->lv[l + 1].w : 0, h2 = exact ? py->lv[l + 1].h : 0;
-      if (l == 0) {
-        // the planar level-0 image is only materialised when the generic resize below needs it
-        float *img0 = (!last && !exact) ? a.img : nullptr;
-        if (int rc = launch_level_u8(ctx, s, src, src_stride, a, smooth0, exact ? &pyr : nullptr,
-                                     gradg, gradd, img0, down, w2, h2))
-          return rc;
-      } else {
-        if (int rc = launch_level_f32(ctx, s, a, exact ? &pyr : nullptr, gradg, gradd, down, w2, h2))
-          return rc;
-      }
-      if (!last && !exact) {
-        const Level &b = py->lv[l + 1];
-        if (int rc = launch_smooth_f32(ctx, s, a.img, a.w, a.h, pyr, py->tmp, GKLT_K_DOWN)) return rc;
-        if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
-      }
-    }
-    return 0;
-  }
-
+// separate kernels: smooth -> (smooth + decimate)* -> gradients of all levels
+int enqueue_build_unfused(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
+                          int src_stride, const BuildTaps &t) {
+  using namespace gklt;
+  const int W = py->lv[0].w, H = py->lv[0].h;
   // pyramid.cpp:59-61  u8 -> f32 -> smooth
-  if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, smooth0, py->lv[0].img)) return rc;
+  if (int rc = launch_smooth_u8(ctx, s, src, src_stride, W, H, t.smooth0, py->lv[0].img)) return rc;
   for (int l = 1; l < py->nlevels; ++l) {  // pyramid.cpp:62-66
     const Level &a = py->lv[l - 1], &b = py->lv[l];
     if (a.w == 2 * b.w && a.h == 2 * b.h) {
-      if (int rc = launch_smooth_decimate2(ctx, s, a.img, a.w, a.h, pyr, b.img, b.w, b.h)) return rc;
+      if (int rc = launch_smooth_decimate2(ctx, s, a.img, a.w, a.h, t.pyr, b.img, b.w, b.h)) return rc;
     } else {
-      if (int rc = launch_smooth_f32(ctx, s, a.img, a.w, a.h, pyr, py->tmp, GKLT_K_DOWN)) return rc;
+      if (int rc = launch_smooth_f32(ctx, s, a.img, a.w, a.h, t.pyr, py->tmp, GKLT_K_DOWN)) return rc;
       if (int rc = launch_resize_linear(ctx, s, py->tmp, a.w, a.h, b.img, b.w, b.h)) return rc;
     }
   }
   // pyramid.cpp:72-83: gradients of every level in one launch
-  return launch_gradients_tex(ctx, s, py->lv, 0, py->nlevels, gradg, gradd);
+  return launch_gradients_tex(ctx, s, py->lv, 0, py->nlevels, t.gradg, t.gradd);
+}
+}  // namespace
+
+int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py,
+                              const uint8_t *const *src, int n, int src_stride) {
+  if (n < 1 || n > GKLT_MAX_LOOKAHEAD) return GKLT_EINVAL;
+  const gklt_pyramid *p0 = py[0];
+  BuildTaps t;
+  if (int rc = build_taps(ctx->prm, p0->nlevels, &t)) return rc;
+
+  // One fused launch per level (for the whole batch) when the radii are the instantiated ones
+  // (the reference's defaults); level l+1 must be an exact 2x decimation for the fused
+  // down-sampling, otherwise that step takes the generic smooth + bilinear resize.
+  const bool fuse = ctx->pyr_impl != 1 &&
+                    level_fusable(&t.smooth0, p0->nlevels > 1 ? &t.pyr : nullptr, t.gradg, t.gradd);
+  if (!fuse) {
+    for (int i = 0; i < n; ++i)
+      if (int rc = enqueue_build_unfused(ctx, s, py[i], src[i], src_stride, t)) return rc;
+    return 0;
+  }
+  for (int l = 0; l < p0->nlevels; ++l) {
+    const Level &a = p0->lv[l];
+    const bool last = l + 1 == p0->nlevels;
+    const bool exact = !last && a.w == 2 * p0->lv[l + 1].w && a.h == 2 * p0->lv[l + 1].h;
+    const bool resize = !last && !exact;
+    if (l == 0 && resize && n > 1) {
+      // the planar level-0 image has to be materialised for the generic resize: frame by frame
+      for (int i = 0; i < n; ++i)
+        if (int rc = launch_level(ctx, s, py + i, src + i, 1, src_stride, 0, t.smooth0, nullptr,
+                                  t.gradg, t.gradd, py[i]->lv[0].img))
+          return rc;
+    } else {
+      if (int rc = launch_level(ctx, s, py, src, n, src_stride, l, t.smooth0,
+                                exact ? &t.pyr : nullptr, t.gradg, t.gradd,
+                                (l == 0 && resize) ? py[0]->lv[0].img : nullptr))
+        return rc;
+    }
+    if (resize) {
+      for (int i = 0; i < n; ++i) {
+        const Level &ai = py[i]->lv[l], &bi = py[i]->lv[l + 1];
+        if (int rc = launch_smooth_f32(ctx, s, ai.img, ai.w, ai.h, t.pyr, py[i]->tmp, GKLT_K_DOWN))
+          return rc;
+        if (int rc = launch_resize_linear(ctx, s, py[i]->tmp, ai.w, ai.h, bi.img, bi.w, bi.h))
+          return rc;
+      }
+    }
+  }
+  return 0;
 }
 
 extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level, int plane,

@@ -126,11 +126,9 @@ int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int 
                             const Taps &g, const Taps &d, float *gx, float *gy);
 // fused level kernels (one launch per level): see gklt_pyramid.hip
 bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d);
-int launch_level_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, const Level &L,
-                    const Taps &s0, const Taps *pyr, const Taps &g, const Taps &d, float *img_out,
-                    float *down, int w2, int h2);
-int launch_level_f32(gklt_ctx *ctx, hipStream_t s, const Level &L, const Taps *pyr, const Taps &g,
-                     const Taps &d, float *down, int w2, int h2);
+int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
+                 int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
+                 const Taps &d, float *img0_out);
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);
 int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp, const float *src);
 
@@ -139,8 +137,16 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
                  int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
                  double *d_vec, unsigned long long *stats, float *mirror = nullptr,
                  int mirror_stride = 0);
+int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const *py, int nframes,
+                        int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
+                        double *d_vec, unsigned long long *stats, float *const *mirrors,
+                        int mirror_stride);
 // all launches of one pyramid build on stream s (gklt_api.hip)
 int enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
                   int src_stride);
+// the same for n same-sized pyramids (n <= GKLT_MAX_LOOKAHEAD): fused levels take one launch per
+// level for the whole batch
+int enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py,
+                        const uint8_t *const *src, int n, int src_stride);
 
 }  // namespace gklt

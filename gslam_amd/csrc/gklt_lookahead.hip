@@ -1,0 +1,244 @@
+// gklt_lookahead: the frame loop of System::Track (System.cpp:501-518) for callers that have the
+// next frames at hand (recorded video, a capture queue).  The reference preloads ONE pyramid ahead
+// on a std::thread (PyramidBuffer, System.h:30-56); here the preload depth is a batch of up to
+// GKLT_MAX_LOOKAHEAD frames, because pyramids do not depend on tracking results at all and the
+// tracker chain of one feature does not depend on other features:
+//   * the pyramids of a batch are built by ONE launch per level (blockIdx.z = frame);
+//   * the previous batch is tracked by ONE launch in which every wavefront follows its feature
+//     through all frame pairs of the batch (k_track_w, multi-frame), writing the list after each
+//     frame into that frame's pinned host buffer.
+// Results are those of frame-at-a-time calls, bit for bit.  Per batch the host enqueues
+// nlevels + 1 launches and two event waits, independent of the batch size.
+//
+// Streams: P builds, T tracks.  submit(k) enqueues  P: wait(T done k-1); build batch k
+//                                                   T: wait(P done k-1); track batch k-1
+// so build(k) overlaps track(k-1).  The ring holds 2*max_batch+1 pyramids: batch k overwrites the
+// slots of frames that the tracker launch of submit(k-1) was the last to read.
+#include <vector>
+
+#include "gklt_internal.h"
+
+using namespace gklt;
+
+struct gklt_lookahead {
+  gklt_ctx *ctx = nullptr;
+  int W = 0, H = 0, max_batch = 0;
+  std::vector<gklt_pyramid *> ring;
+  gklt_flist *fl = nullptr;
+  hipStream_t sp = nullptr, st = nullptr;
+  hipEvent_t e_built = nullptr, e_tracked = nullptr;
+  bool has_built = false, has_tracked = false;
+  std::vector<uint8_t *> stage;  // per batch position: staging of host frames
+  long built = -1;               // last frame whose pyramid has been enqueued
+  long tracked = 0;              // last frame the list has been tracked to (enqueued)
+  float *pending_mirror[GKLT_MAX_LOOKAHEAD] = {};  // device views of host_out of pending frames
+  void *pending_host[GKLT_MAX_LOOKAHEAD] = {};     // unpinned host_out: copied after the launch
+  bool started = false;
+};
+
+static gklt_pyramid *slot(gklt_lookahead *p, long frame) {
+  return p->ring[(size_t)(frame % (long)p->ring.size())];
+}
+
+extern "C" int gklt_lookahead_create(gklt_ctx *ctx, int width, int height, int capacity,
+                                     int max_batch, gklt_lookahead **out) {
+  if (!ctx || !out || width < 1 || height < 1 || capacity < 1 || max_batch < 1 ||
+      max_batch > GKLT_MAX_LOOKAHEAD)
+    return GKLT_EINVAL;
+  *out = nullptr;
+  GKLT_HIP(hipSetDevice(ctx->device));
+  gklt_lookahead *p = new gklt_lookahead();
+  p->ctx = ctx;
+  p->W = width;
+  p->H = height;
+  p->max_batch = max_batch;
+  int rc = 0;
+  p->ring.assign((size_t)2 * max_batch + 1, nullptr);
+  for (size_t i = 0; i < p->ring.size() && !rc; ++i)
+    rc = gklt_pyramid_create(ctx, width, height, &p->ring[i]);
+  if (!rc) rc = gklt_flist_create(ctx, capacity, &p->fl);
+  if (!rc && (hipStreamCreateWithFlags(&p->sp, hipStreamNonBlocking) != hipSuccess ||
+              hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess ||
+              hipEventCreateWithFlags(&p->e_built, hipEventDisableTiming) != hipSuccess ||
+              hipEventCreateWithFlags(&p->e_tracked, hipEventDisableTiming) != hipSuccess)) {
+    set_error("lookahead streams/events could not be created");
+    rc = GKLT_EHIP;
+  }
+  if (rc) {
+    gklt_lookahead_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int gklt_lookahead_sync(gklt_lookahead *p) {
+  if (!p) return GKLT_EINVAL;
+  GKLT_HIP(hipSetDevice(p->ctx->device));
+  if (p->sp) GKLT_HIP(hipStreamSynchronize(p->sp));
+  if (p->st) GKLT_HIP(hipStreamSynchronize(p->st));
+  return 0;
+}
+
+extern "C" int gklt_lookahead_destroy(gklt_lookahead *p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->ctx->device);
+  if (p->sp) (void)hipStreamSynchronize(p->sp);
+  if (p->st) (void)hipStreamSynchronize(p->st);
+  for (auto *py : p->ring) gklt_pyramid_destroy(py);
+  gklt_flist_destroy(p->fl);
+  for (auto *b : p->stage)
+    if (b) (void)hipFree(b);
+  if (p->e_built) (void)hipEventDestroy(p->e_built);
+  if (p->e_tracked) (void)hipEventDestroy(p->e_tracked);
+  if (p->sp) (void)hipStreamDestroy(p->sp);
+  if (p->st) (void)hipStreamDestroy(p->st);
+  delete p;
+  return 0;
+}
+
+extern "C" gklt_flist *gklt_lookahead_flist(gklt_lookahead *p) { return p ? p->fl : nullptr; }
+
+// build of frames [first, first+n) on stream P
+static int enqueue_batch_build(gklt_lookahead *p, long first, const uint8_t *const *frames, int n,
+                               int stride, int on_device) {
+  gklt_pyramid *py[GKLT_MAX_LOOKAHEAD];
+  const uint8_t *src[GKLT_MAX_LOOKAHEAD];
+  int src_stride = stride;
+  if (!on_device) {
+    if (p->stage.size() < (size_t)p->max_batch) p->stage.resize((size_t)p->max_batch, nullptr);
+    src_stride = p->W;
+  }
+  for (int i = 0; i < n; ++i) {
+    py[i] = slot(p, first + i);
+    if (on_device) {
+      src[i] = frames[i];
+    } else {
+      if (!p->stage[i] && hipMalloc(&p->stage[i], (size_t)p->W * p->H) != hipSuccess) {
+        set_error("out of device memory for the frame staging buffer");
+        return GKLT_ENOMEM;
+      }
+      GKLT_HIP(hipMemcpy2DAsync(p->stage[i], p->W, frames[i], stride, p->W, p->H,
+                                hipMemcpyHostToDevice, p->sp));
+      src[i] = p->stage[i];
+    }
+  }
+  if (int rc = enqueue_build_batch(p->ctx, p->sp, py, src, n, src_stride)) return rc;
+  for (int i = 0; i < n; ++i) py[i]->has_ready = true;
+  return 0;
+}
+
+// the list is tracked from frame p->tracked to frame p->built on stream T (one launch)
+static int enqueue_pending_track(gklt_lookahead *p) {
+  const int nf = (int)(p->built - p->tracked);
+  if (nf <= 0) return 0;
+  if (p->has_built) GKLT_HIP(hipStreamWaitEvent(p->st, p->e_built, 0));
+  const gklt_pyramid *py[GKLT_MAX_LOOKAHEAD + 1];
+  for (int j = 0; j <= nf; ++j) py[j] = slot(p, p->tracked + j);
+  gklt_flist *fl = p->fl;
+  bool copies = false;
+  for (int j = 0; j < nf; ++j) copies = copies || p->pending_host[j];
+  if (!copies) {
+    if (int rc = launch_track_frames(p->ctx, p->st, py, nf, fl->n, fl->x, fl->y, fl->val, nullptr,
+                                     nullptr, nullptr, fl->stats, p->pending_mirror, fl->capacity))
+      return rc;
+  } else {
+    // some host_out buffer is not pinned: frame-at-a-time launches with a copy after each
+    for (int j = 0; j < nf; ++j) {
+      if (int rc = launch_track_frames(p->ctx, p->st, py + j, 1, fl->n, fl->x, fl->y, fl->val,
+                                       nullptr, nullptr, nullptr, fl->stats, p->pending_mirror + j,
+                                       fl->capacity))
+        return rc;
+      if (p->pending_host[j])
+        GKLT_HIP(hipMemcpyAsync(p->pending_host[j], fl->x, 3 * sizeof(float) * (size_t)fl->capacity,
+                                hipMemcpyDeviceToHost, p->st));
+    }
+  }
+  GKLT_HIP(hipEventRecord(p->e_tracked, p->st));
+  p->has_tracked = true;
+  p->tracked = p->built;
+  for (int j = 0; j < GKLT_MAX_LOOKAHEAD; ++j) {
+    p->pending_mirror[j] = nullptr;
+    p->pending_host[j] = nullptr;
+  }
+  return 0;
+}
+
+extern "C" int gklt_lookahead_start(gklt_lookahead *p, const uint8_t *img0, int stride,
+                                    int on_device) {
+  if (!p || !img0 || stride < p->W) return GKLT_EINVAL;
+  if (int rc = gklt_lookahead_sync(p)) return rc;
+  p->has_built = p->has_tracked = false;
+  p->built = -1;
+  p->tracked = 0;
+  if (int rc = enqueue_batch_build(p, 0, &img0, 1, stride, on_device)) return rc;
+  if (int rc = gklt_lookahead_sync(p)) return rc;
+  p->built = 0;
+  p->started = true;
+  return 0;
+}
+
+extern "C" int gklt_lookahead_submit(gklt_lookahead *p, const uint8_t *const *frames, int n,
+                                     int stride, int on_device, void *const *host_out) {
+  if (!p || !p->started || !frames || n < 1 || n > p->max_batch || stride < p->W) return GKLT_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!frames[i]) return GKLT_EINVAL;
+  gklt_ctx *ctx = p->ctx;
+  GKLT_HIP(hipSetDevice(ctx->device));
+  if (p->ring[0]->nlevels != ctx->prm.nPyramidLevels || p->ring[0]->ss != ctx->prm.subsampling) {
+    set_error("context levels/subsampling changed after the lookahead pipeline was created");
+    return GKLT_EINVAL;
+  }
+  // P: build this batch.  Its ring slots were last read by the tracker launch of the PREVIOUS
+  // call (e_tracked still holds that record: the wait is enqueued before the re-record below), so
+  // the build does not wait for the launch enqueued next and overlaps it.
+  if (p->has_tracked) GKLT_HIP(hipStreamWaitEvent(p->sp, p->e_tracked, 0));
+  if (int rc = enqueue_batch_build(p, p->built + 1, frames, n, stride, on_device)) return rc;
+  // T: track the batch submitted by the previous call; waits for e_built's previous record (that
+  // batch's build), which is why e_built is re-recorded only afterwards
+  if (int rc = enqueue_pending_track(p)) return rc;
+  GKLT_HIP(hipEventRecord(p->e_built, p->sp));
+  p->has_built = true;
+  for (int i = 0; i < n; ++i) {
+    p->pending_mirror[i] = nullptr;
+    p->pending_host[i] = nullptr;
+    void *h = host_out ? host_out[i] : nullptr;
+    if (!h) continue;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, h, 0) == hipSuccess && dp) {
+      p->pending_mirror[i] = static_cast<float *>(dp);
+    } else {
+      (void)hipGetLastError();
+      p->pending_host[i] = h;
+    }
+  }
+  p->built += n;
+  return 0;
+}
+
+extern "C" int gklt_lookahead_flush(gklt_lookahead *p) {
+  if (!p || !p->started) return GKLT_EINVAL;
+  GKLT_HIP(hipSetDevice(p->ctx->device));
+  if (int rc = enqueue_pending_track(p)) return rc;
+  return gklt_lookahead_sync(p);
+}
+
+extern "C" int gklt_lookahead_upload_features(gklt_lookahead *p, int n, const float *x,
+                                              const float *y, const int *val) {
+  if (!p || n < 0 || (n > 0 && (!x || !y || !val))) return GKLT_EINVAL;
+  if (n > p->fl->capacity) {
+    set_error("%d features exceed the list capacity %d", n, p->fl->capacity);
+    return GKLT_ECAPACITY;
+  }
+  GKLT_HIP(hipSetDevice(p->ctx->device));
+  // stream T: after the last tracker launch, before the next one
+  if (n > 0) {
+    GKLT_HIP(hipMemcpyAsync(p->fl->x, x, sizeof(float) * n, hipMemcpyHostToDevice, p->st));
+    GKLT_HIP(hipMemcpyAsync(p->fl->y, y, sizeof(float) * n, hipMemcpyHostToDevice, p->st));
+    GKLT_HIP(hipMemcpyAsync(p->fl->val, val, sizeof(int) * n, hipMemcpyHostToDevice, p->st));
+  }
+  p->fl->n = n;
+  return 0;
+}
+
+extern "C" long gklt_lookahead_frames_tracked(gklt_lookahead *p) { return p ? p->tracked : -1; }

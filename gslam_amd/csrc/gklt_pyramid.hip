@@ -496,11 +496,20 @@ __device__ __forceinline__ void load_groups(const float *p, float (&v)[4 * NG]) 
   }
 }
 
+// blockIdx.z = frame of the batch (lookahead builds put several frames into one launch)
+struct LevelIO {
+  const void *src[GKLT_MAX_LOOKAHEAD];
+  Texel *tex[GKLT_MAX_LOOKAHEAD];
+  float *down[GKLT_MAX_LOOKAHEAD];
+};
+
 template <typename SrcT, int R0, int RP, int RG, bool DOWN>
-__global__ __launch_bounds__(NT) void k_level(const SrcT *__restrict__ src, int stride, int w,
-                                              int h, Taps s0, Taps pyr, Taps g, Taps d,
-                                              Texel *__restrict__ tex, float *__restrict__ img_out,
-                                              float *__restrict__ down, int w2, int h2) {
+__global__ __launch_bounds__(NT) void k_level(LevelIO io, int stride, int w, int h, Taps s0,
+                                              Taps pyr, Taps g, Taps d,
+                                              float *__restrict__ img_out, int w2, int h2) {
+  const SrcT *__restrict__ src = static_cast<const SrcT *>(io.src[blockIdx.z]);
+  Texel *__restrict__ tex = io.tex[blockIdx.z];
+  float *__restrict__ down = io.down[blockIdx.z];
   constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
   using G = LevelGeom<R0, HI>;
   constexpr int GH = TH + 2 * RG;  // rows of the gradient row pass
@@ -745,15 +754,16 @@ int launch_grad_batch(gklt_ctx *ctx, hipStream_t s, GradBatch &b, const Taps &g,
 }
 
 template <typename SrcT, int R0, bool DOWN>
-int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const SrcT *src, int stride,
-                      const Level &L, const Taps &s0, const Taps &pyr, const Taps &g, const Taps &d,
-                      float *img_out, float *down, int w2, int h2) {
+int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const LevelIO &io, int nframes,
+                      int stride, int w, int h, const Taps &s0, const Taps &pyr, const Taps &g,
+                      const Taps &d, float *img_out, int w2, int h2) {
   auto kern = k_level<SrcT, R0, 5, 3, DOWN>;
   constexpr size_t lds = level_lds<R0, 5, 3, DOWN>();
   static_assert(lds <= 48 * 1024, "fused level kernel fits the default LDS limit");
+  dim3 grid = tile_grid(w, h);
+  grid.z = nframes;
   ProfScope ps(ctx, s, prof_id);
-  hipLaunchKernelGGL(kern, tile_grid(L.w, L.h), dim3(NT), lds, s, src, stride, L.w, L.h, s0, pyr, g,
-                     d, L.tex, img_out, down, w2, h2);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, io, stride, w, h, s0, pyr, g, d, img_out, w2, h2);
   GKLT_HIP(hipGetLastError());
   return 0;
 }
@@ -769,16 +779,38 @@ bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d
   return true;
 }
 
-int launch_level_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, const Level &L,
-                    const Taps &s0, const Taps *pyr, const Taps &g, const Taps &d, float *img_out,
-                    float *down, int w2, int h2) {
+// Level `level` of `n` pyramids in one launch (n <= GKLT_MAX_LOOKAHEAD).  Level 0 reads the u8
+// frames src[i] (smoothing s0); level l > 0 reads py[i]->lv[l].img.  pyr == nullptr: no
+// down-sampling (last level, or the next level is not an exact 2x decimation).  img0_out (single
+// frame only) additionally materialises the planar level-0 image.
+int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
+                 int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
+                 const Taps &d, float *img0_out) {
+  if (n < 1 || n > GKLT_MAX_LOOKAHEAD || (img0_out && n != 1)) return GKLT_EINVAL;
+  LevelIO io{};
+  const Level &L = py[0]->lv[level];
+  int w2 = 0, h2 = 0;
+  for (int i = 0; i < n; ++i) {
+    const Level &Li = py[i]->lv[level];
+    if (Li.w != L.w || Li.h != L.h) return GKLT_EINVAL;
+    io.src[i] = level == 0 ? static_cast<const void *>(src[i]) : static_cast<const void *>(Li.img);
+    io.tex[i] = Li.tex;
+    io.down[i] = pyr ? py[i]->lv[level + 1].img : nullptr;
+  }
+  if (pyr) { w2 = py[0]->lv[level + 1].w; h2 = py[0]->lv[level + 1].h; }
   const Taps &p = pyr ? *pyr : g;
-#define GKLT_LEVEL_CASE(RR)                                                                       \
-  case RR:                                                                                        \
-    return down ? launch_level_inst<uint8_t, RR, true>(ctx, s, GKLT_K_LEVEL0, src, stride, L, s0, \
-                                                       p, g, d, img_out, down, w2, h2)            \
-                : launch_level_inst<uint8_t, RR, false>(ctx, s, GKLT_K_LEVEL0, src, stride, L,    \
-                                                        s0, p, g, d, img_out, nullptr, 0, 0);
+  if (level > 0) {
+    return pyr ? launch_level_inst<float, 0, true>(ctx, s, GKLT_K_LEVELN, io, n, L.w, L.w, L.h, g, p,
+                                                   g, d, nullptr, w2, h2)
+               : launch_level_inst<float, 0, false>(ctx, s, GKLT_K_LEVELN, io, n, L.w, L.w, L.h, g,
+                                                    p, g, d, nullptr, 0, 0);
+  }
+#define GKLT_LEVEL_CASE(RR)                                                                        \
+  case RR:                                                                                         \
+    return pyr ? launch_level_inst<uint8_t, RR, true>(ctx, s, GKLT_K_LEVEL0, io, n, stride, L.w,   \
+                                                      L.h, s0, p, g, d, img0_out, w2, h2)          \
+               : launch_level_inst<uint8_t, RR, false>(ctx, s, GKLT_K_LEVEL0, io, n, stride, L.w,  \
+                                                       L.h, s0, p, g, d, img0_out, 0, 0);
   switch (s0.r) {
     GKLT_LEVEL_CASE(1)
     GKLT_LEVEL_CASE(2)
@@ -788,15 +820,6 @@ int launch_level_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride
 #undef GKLT_LEVEL_CASE
   set_error("fused level kernel: unsupported level-0 radius %d", s0.r);
   return GKLT_EINVAL;
-}
-
-int launch_level_f32(gklt_ctx *ctx, hipStream_t s, const Level &L, const Taps *pyr, const Taps &g,
-                     const Taps &d, float *down, int w2, int h2) {
-  const Taps &p = pyr ? *pyr : g;
-  return down ? launch_level_inst<float, 0, true>(ctx, s, GKLT_K_LEVELN, L.img, L.w, L, g, p, g, d,
-                                                  nullptr, down, w2, h2)
-              : launch_level_inst<float, 0, false>(ctx, s, GKLT_K_LEVELN, L.img, L.w, L, g, p, g, d,
-                                                   nullptr, nullptr, 0, 0);
 }
 
 int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,

@@ -43,6 +43,15 @@ struct TrackArgs {
   int mirror_stride;
 };
 
+// Multi-frame launches (lookahead pipeline): a wavefront follows its feature through nframes
+// consecutive frame pairs (tex[j], tex[j+1]); features are independent of each other, so this is
+// the same computation as nframes launches, without the launch boundaries in between.
+struct TrackFrames {
+  const Texel *tex[GKLT_MAX_LOOKAHEAD + 1][GKLT_MAX_LEVELS];
+  float *mirror[GKLT_MAX_LOOKAHEAD];  // per frame: host-visible x | y | val (or nullptr)
+  int nframes;
+};
+
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
 constexpr int kStatShards = GKLT_STAT_SHARDS;
 
@@ -355,7 +364,8 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // instead of four gathers per element.
 // FPL = footprint texels per lane (0 = no staging).
 template <int EPL, int FPL>
-__global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__ fx,
+__global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
+                                                float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
                                                 const double *__restrict__ invk,
                                                 double *__restrict__ norm3,
@@ -376,15 +386,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
   const int FW = ww + 1, NF = FW * (wh + 1);
 
   const int val0 = fval[f];
-  float xloc = fx[f], yloc = fy[f];
-  if (val0 < 0) {  // LK.hpp:830: lost features are not touched
-    if (a.mirror && lane == 0) {
-      a.mirror[f] = xloc;
-      a.mirror[a.mirror_stride + f] = yloc;
-      reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = val0;
-    }
-    return;
-  }
+  float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
+  int vcur = val0;
   // element -> texel offset inside the window (tail elements clamp to the last pixel, value 0)
   int eoff_x[EPL], eoff_y[EPL];
   bool evalid[EPL];
@@ -457,17 +460,28 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
       tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), q));
   };
 
+  int iters_total = 0, ntracked = 0;
+  for (int fr = 0; fr < F.nframes; ++fr) {
+  if (vcur < 0) {  // LK.hpp:830: lost features are not touched
+    if (F.mirror[fr] && lane == 0) {
+      float *m = F.mirror[fr];
+      m[f] = px;
+      m[a.mirror_stride + f] = py;
+      reinterpret_cast<int *>(m)[2 * a.mirror_stride + f] = vcur;
+    }
+    continue;
+  }
+  float xloc = px, yloc = py;
   for (int r = 0; r < a.nlevels; ++r) { xloc /= a.ss; yloc /= a.ss; }  // LK.hpp:837-839
   float xo = xloc, yo = yloc;
   int v = GKLT_TRACKED;
-  int iters_total = 0;
 
   for (int r = a.nlevels - 1; r >= 0; --r) {  // LK.hpp:859-881
     xloc *= a.ss; yloc *= a.ss;
     xo *= a.ss; yo *= a.ss;
     // ---- _trackFeature, LK.hpp:413-669 ----
-    const TrackLevel L = a.lv[r];
-    const int nc = L.nc, nr = L.nr;
+    const int nc = a.lv[r].nc, nr = a.lv[r].nr;
+    const Texel *const lt1 = F.tex[fr][r], *const lt2 = F.tex[fr + 1][r];
     int status = GKLT_TRACKED, iteration = 0;
     const float x1 = xloc, y1 = yloc;
     float x2 = xo, y2 = yo;
@@ -477,10 +491,10 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
     } else {
       Bilin b1 = bilinear_weight(x1, y1);
       clamp_origin(b1, hw, hh, nc, nr);
-      const Texel *o1 = L.t1 + (size_t)(b1.yt - hh) * nc + (b1.xt - hw);
+      const Texel *o1 = lt1 + (size_t)(b1.yt - hh) * nc + (b1.xt - hw);
       Bilin b2 = bilinear_weight(x2, y2);  // :568-572
       clamp_origin(b2, hw, hh, nc, nr);
-      const Texel *o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+      const Texel *o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
       float3 T1[EPL], S2[EPL];
       if (STAGE) {
         float3 f1[FP], f2[FP];
@@ -540,7 +554,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
         if (window_oob(x2, y2, hw, hh, nc, nr)) { status = GKLT_OOB; break; }  // next pass :558
         b2 = bilinear_weight(x2, y2);
         clamp_origin(b2, hw, hh, nc, nr);
-        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         if (STAGE) {
           float3 f2[FP];
           fp_load(o2, nc, f2);
@@ -561,7 +575,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
       if (status == GKLT_TRACKED && r == 0) {
         b2 = bilinear_weight(x2, y2);
         clamp_origin(b2, hw, hh, nc, nr);
-        o2 = L.t2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
+        o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         float sI[EPL];
         if (STAGE) {
           float3 f2[FP];
@@ -600,21 +614,22 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
                    yo > a.h0 - 1 - a.bordery;  // _outOfBounds :185-191
   const int out = (v == GKLT_OOB || oob) ? GKLT_OOB : v;
   const bool tracked = out == GKLT_TRACKED;
+  px = tracked ? xo : -1.0f;
+  py = tracked ? yo : -1.0f;
+  vcur = out;
+  ntracked += tracked;
   if (lane == 0) {
-    const float ox = tracked ? xo : -1.0f, oy = tracked ? yo : -1.0f;
-    fx[f] = ox;
-    fy[f] = oy;
-    fval[f] = out;
-    if (a.mirror) {
-      a.mirror[f] = ox;
-      a.mirror[a.mirror_stride + f] = oy;
-      reinterpret_cast<int *>(a.mirror)[2 * a.mirror_stride + f] = out;
+    if (F.mirror[fr]) {
+      float *m = F.mirror[fr];
+      m[f] = px;
+      m[a.mirror_stride + f] = py;
+      reinterpret_cast<int *>(m)[2 * a.mirror_stride + f] = out;
     }
     if (tracked && a.do_epilogue) {  // bearing vectors, LK.hpp:1019-1035 (fp64)
-      const double px = (double)xo, py = (double)yo;
+      const double qx = (double)xo, qy = (double)yo;
       double q[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) q[i] = (invk[3 * i] * px + invk[3 * i + 1] * py) + invk[3 * i + 2];
+      for (int i = 0; i < 3; ++i) q[i] = (invk[3 * i] * qx + invk[3 * i + 1] * qy) + invk[3 * i + 2];
       const double nn = sqrt((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]);
       double nv[3];
 #pragma unroll
@@ -622,9 +637,17 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
 #pragma unroll
       for (int i = 0; i < 3; ++i) vec3[3 * (size_t)f + i] = nv[i] / nv[2];
     }
+  }
+  __syncthreads();  // LDS is reused by the next frame
+  }  // frames
+
+  if (val0 >= 0 && lane == 0) {
+    fx[f] = px;
+    fy[f] = py;
+    fval[f] = vcur;
     if (stats) {  // sharded: thousands of adds to one word would serialise at the memory side
       unsigned long long *sh = stats + 2 * (f & (kStatShards - 1));
-      if (tracked) atomicAdd(&sh[0], 1ull);
+      if (ntracked) atomicAdd(&sh[0], (unsigned long long)ntracked);
       atomicAdd(&sh[1], (unsigned long long)iters_total);
     }
   }
@@ -635,21 +658,33 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, float *__restrict__
 int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gklt_pyramid *p2,
                  int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
                  double *d_vec, unsigned long long *stats, float *mirror, int mirror_stride) {
+  const gklt_pyramid *py[2] = {p1, p2};
+  return launch_track_frames(ctx, s, py, 1, n, x, y, val, d_invk, d_norm, d_vec, stats, &mirror,
+                             mirror_stride);
+}
+
+// Tracks the list through nframes consecutive pairs (py[j], py[j+1]), j = 0..nframes-1; mirrors[j]
+// (optional, host-visible) receives the list after frame j.  One launch when the wave-per-feature
+// kernel applies, nframes launches otherwise.
+int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const *py, int nframes,
+                        int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
+                        double *d_vec, unsigned long long *stats, float *const *mirrors,
+                        int mirror_stride) {
   const gklt_params &P = ctx->prm;
-  if (p1->nlevels != P.nPyramidLevels || p2->nlevels != P.nPyramidLevels ||
-      p1->ss != P.subsampling || p2->ss != P.subsampling) {
-    set_error("pyramids were built for %d levels / subsampling %d, context has %d / %d",
-              p1->nlevels, p1->ss, P.nPyramidLevels, P.subsampling);
-    return GKLT_EINVAL;
-  }
-  TrackArgs a{};
-  for (int l = 0; l < P.nPyramidLevels; ++l) {
-    if (p1->lv[l].w != p2->lv[l].w || p1->lv[l].h != p2->lv[l].h) {
-      set_error("pyramid sizes differ at level %d", l);
+  if (nframes < 1 || nframes > GKLT_MAX_LOOKAHEAD) return GKLT_EINVAL;
+  for (int j = 0; j <= nframes; ++j) {
+    if (py[j]->nlevels != P.nPyramidLevels || py[j]->ss != P.subsampling) {
+      set_error("pyramids were built for %d levels / subsampling %d, context has %d / %d",
+                py[j]->nlevels, py[j]->ss, P.nPyramidLevels, P.subsampling);
       return GKLT_EINVAL;
     }
-    a.lv[l] = TrackLevel{p1->lv[l].tex, p2->lv[l].tex, p1->lv[l].w, p1->lv[l].h};
+    for (int l = 0; l < P.nPyramidLevels; ++l)
+      if (py[j]->lv[l].w != py[0]->lv[l].w || py[j]->lv[l].h != py[0]->lv[l].h) {
+        set_error("pyramid sizes differ at level %d", l);
+        return GKLT_EINVAL;
+      }
   }
+  TrackArgs a{};
   a.nlevels = P.nPyramidLevels;
   a.ss = (float)P.subsampling;  // LK.hpp:978
   a.ww = P.window_width;
@@ -659,18 +694,15 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
   a.min_disp = P.min_displacement;
   a.max_residue = P.max_residue;
   a.max_iter = P.max_iterations;
-  a.w0 = p1->lv[0].w;
-  a.h0 = p1->lv[0].h;
+  a.w0 = py[0]->lv[0].w;
+  a.h0 = py[0]->lv[0].h;
   a.borderx = P.borderx;
   a.bordery = P.bordery;
   a.n = n;
   a.do_epilogue = d_invk && d_norm && d_vec;
-  a.mirror = mirror;
   a.mirror_stride = mirror_stride;
   if (n <= 0) return 0;
 
-  const dim3 grid((n + 7) / 8), block(64);
-  ProfScope ps(ctx, s, GKLT_K_TRACK);
   const int NA = 8 * ((a.ww * a.wh + 8) / 8);
   const int NF = (a.ww + 1) * (a.wh + 1);
   // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
@@ -678,10 +710,24 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
   const bool stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && a.ww * a.wh >= 200);
   const int epl = (NA + 63) / 64, fpl = (NF + 63) / 64;
   const size_t wlds = sizeof(float) * (size_t)(5 * NA + 40) + (stage ? sizeof(float4) * (size_t)NF : 0);
-#define GKLT_TRACK_W(E, F)                                                                     \
-  hipLaunchKernelGGL((k_track_w<E, F>), dim3(n), block, wlds, s, a, x, y, val, d_invk, d_norm,   \
-                     d_vec, stats)
+  const dim3 block(64);
+
   if (ctx->track_impl != 1 && epl <= 16 && fpl <= 16 && wlds <= 48 * 1024) {  // feature per wave
+    if (a.do_epilogue && nframes != 1) {
+      set_error("bearing vectors are produced by single-frame launches only");
+      return GKLT_EINVAL;
+    }
+    for (int l = 0; l < P.nPyramidLevels; ++l)
+      a.lv[l] = TrackLevel{nullptr, nullptr, py[0]->lv[l].w, py[0]->lv[l].h};
+    TrackFrames F{};
+    F.nframes = nframes;
+    for (int j = 0; j <= nframes; ++j)
+      for (int l = 0; l < P.nPyramidLevels; ++l) F.tex[j][l] = py[j]->lv[l].tex;
+    for (int j = 0; j < nframes; ++j) F.mirror[j] = mirrors ? mirrors[j] : nullptr;
+    ProfScope ps(ctx, s, GKLT_K_TRACK);
+#define GKLT_TRACK_W(E, FP)                                                                    \
+  hipLaunchKernelGGL((k_track_w<E, FP>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,       \
+                     d_norm, d_vec, stats)
     if (!stage) {
       if (epl <= 1) GKLT_TRACK_W(1, 0);
       else if (epl <= 2) GKLT_TRACK_W(2, 0);
@@ -700,23 +746,35 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
       GKLT_TRACK_W(16, 16);
     }
 #undef GKLT_TRACK_W
-  } else if (a.ww == 7 && a.wh == 7) {
-    hipLaunchKernelGGL((k_track<7, 7>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
-  } else if (a.ww == 11 && a.wh == 11) {
-    hipLaunchKernelGGL((k_track<11, 11>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
-  } else {
-    const int ne = (a.ww * a.wh + 8) / 8;
-    const size_t lds = (size_t)3 * ne * 64 * sizeof(float);
-    if (lds > 160 * 1024) {
-      set_error("window %dx%d needs %zu bytes of LDS per wave (> 160 KiB)", a.ww, a.wh, lds);
-      return GKLT_EINVAL;
-    }
-    if (lds > 48 * 1024)
-      GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_track<0, 0>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_track<0, 0>), grid, block, lds, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+    GKLT_HIP(hipGetLastError());
+    return 0;
   }
-  GKLT_HIP(hipGetLastError());
+
+  // one feature per 8-lane slice: one launch per frame pair
+  const dim3 grid((n + 7) / 8);
+  for (int j = 0; j < nframes; ++j) {
+    for (int l = 0; l < P.nPyramidLevels; ++l)
+      a.lv[l] = TrackLevel{py[j]->lv[l].tex, py[j + 1]->lv[l].tex, py[0]->lv[l].w, py[0]->lv[l].h};
+    a.mirror = mirrors ? mirrors[j] : nullptr;
+    ProfScope ps(ctx, s, GKLT_K_TRACK);
+    if (a.ww == 7 && a.wh == 7) {
+      hipLaunchKernelGGL((k_track<7, 7>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+    } else if (a.ww == 11 && a.wh == 11) {
+      hipLaunchKernelGGL((k_track<11, 11>), grid, block, 0, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+    } else {
+      const int ne = (a.ww * a.wh + 8) / 8;
+      const size_t lds = (size_t)3 * ne * 64 * sizeof(float);
+      if (lds > 160 * 1024) {
+        set_error("window %dx%d needs %zu bytes of LDS per wave (> 160 KiB)", a.ww, a.wh, lds);
+        return GKLT_EINVAL;
+      }
+      if (lds > 48 * 1024)
+        GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_track<0, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL((k_track<0, 0>), grid, block, lds, s, a, x, y, val, d_invk, d_norm, d_vec, stats);
+    }
+    GKLT_HIP(hipGetLastError());
+  }
   return 0;
 }
 

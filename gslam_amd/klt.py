@@ -383,6 +383,62 @@ class Pipeline:
             self.h = C.c_void_p()
 
 
+class Lookahead:
+    """gklt_lookahead: the frame loop with batches of frames handed over ahead of time."""
+
+    def __init__(self, ctx, W, H, capacity, max_batch):
+        L = lib()
+        L.gklt_lookahead_flist.restype = C.c_void_p
+        L.gklt_lookahead_frames_tracked.restype = C.c_long
+        self.ctx, self.W, self.H, self.capacity, self.max_batch = ctx, W, H, capacity, max_batch
+        self.h = C.c_void_p()
+        _check(L.gklt_lookahead_create(ctx.h, W, H, capacity, max_batch, C.byref(self.h)))
+        self.flist = FeatureList.__new__(FeatureList)
+        self.flist.ctx, self.flist.capacity = ctx, capacity
+        self.flist.h = C.c_void_p(L.gklt_lookahead_flist(self.h))
+        self._keep = []
+
+    def start(self, img0):
+        keep, p, s, d = Pipeline._img(img0)
+        _check(lib().gklt_lookahead_start(self.h, p, s, d))
+
+    def submit(self, frames, host_out=None):
+        """frames: list of numpy u8 images or of (device pointer, stride); host_out: list of
+        host addresses (pinned or not) or None."""
+        n = len(frames)
+        parts = [Pipeline._img(f) for f in frames]
+        strides = {q[2] for q in parts}
+        dev = {q[3] for q in parts}
+        assert len(strides) == 1 and len(dev) == 1
+        arr = (C.POINTER(C.c_uint8) * n)(*[q[1] for q in parts])
+        outs = None
+        if host_out is not None:
+            outs = (C.c_void_p * n)(*[C.c_void_p(h) for h in host_out])
+        _check(lib().gklt_lookahead_submit(self.h, arr, n, strides.pop(), dev.pop(), outs))
+        if parts[0][0] is not None:
+            _check(lib().gklt_lookahead_sync(self.h))  # pageable host frames must stay alive until staged
+
+    def flush(self):
+        _check(lib().gklt_lookahead_flush(self.h))
+
+    def sync(self):
+        _check(lib().gklt_lookahead_sync(self.h))
+
+    def upload_features(self, x, y, val):
+        self._seed = (np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32),
+                      np.ascontiguousarray(val, np.int32))
+        x, y, val = self._seed
+        _check(lib().gklt_lookahead_upload_features(self.h, len(x), _fp(x), _fp(y), _ip(val)))
+
+    def frames_tracked(self):
+        return lib().gklt_lookahead_frames_tracked(self.h)
+
+    def close(self):
+        if self.h:
+            lib().gklt_lookahead_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def KLTTrackFeatures(ctx, pyr1, pyr2, x, y, val, invK=None):
     """LK.hpp:972 -- returns updated copies (x, y, val[, norm, vec])."""
     x = np.array(x, np.float32)

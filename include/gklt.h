@@ -23,6 +23,7 @@ extern "C" {
 
 #define GKLT_MAX_KERNEL_WIDTH 71 /* KLT.h:107 MAX_KERNEL_WIDTH */
 #define GKLT_MAX_LEVELS 12
+#define GKLT_MAX_LOOKAHEAD 16 /* frames per batched build / multi-frame tracker launch */
 
 /* KLT.h:69-74 */
 #define GKLT_TRACKED 0
@@ -201,6 +202,39 @@ int gklt_pipeline_sync(gklt_pipeline *p);
  * call gklt_pipeline_sync() first. */
 gklt_flist *gklt_pipeline_flist(gklt_pipeline *p);
 gklt_pyramid *gklt_pipeline_pyramid(gklt_pipeline *p, int which);
+
+/* ---- lookahead pipeline: the same frame loop with a deeper preload ---- */
+
+/* The reference preloads ONE pyramid ahead on a std::thread (System.cpp:508-511,
+ * PyramidBuffer System.h:30-56).  A caller that has the next frames at hand (recorded video, a
+ * capture queue) can hand over up to max_batch (<= GKLT_MAX_LOOKAHEAD) frames per call:
+ * gklt_lookahead_submit() builds their pyramids with one launch per level for the whole batch
+ * and, overlapped with that, tracks the batch submitted by the PREVIOUS call with a single
+ * launch in which each feature is followed through all frames of that batch.  The lists are those
+ * of frame-at-a-time gklt_pipeline_step() calls, bit for bit; they arrive one call later.
+ *   start(img0)                       pyramid of frame 0; the list is frame 0's (upload_features)
+ *   submit(frames[0..n), host_out[])  frames built+1 .. built+n; host_out[i] (may be NULL, same
+ *                                     layout and pinning rule as gklt_pipeline_step) receives the
+ *                                     list after frame i of THIS batch, written when the batch is
+ *                                     tracked: by the next submit()/flush(), so the buffers must
+ *                                     stay valid until then
+ *   flush()                           tracks what is still pending and synchronises
+ *   upload_features()                 replaces the list before the next tracker launch, i.e. from
+ *                                     the first frame that has been submitted but not yet tracked */
+typedef struct gklt_lookahead gklt_lookahead;
+int gklt_lookahead_create(gklt_ctx *ctx, int width, int height, int capacity, int max_batch,
+                          gklt_lookahead **out);
+int gklt_lookahead_destroy(gklt_lookahead *p);
+int gklt_lookahead_start(gklt_lookahead *p, const uint8_t *img0, int stride, int img_on_device);
+int gklt_lookahead_submit(gklt_lookahead *p, const uint8_t *const *frames, int n, int stride,
+                          int img_on_device, void *const *host_out);
+int gklt_lookahead_flush(gklt_lookahead *p);
+int gklt_lookahead_upload_features(gklt_lookahead *p, int n, const float *x, const float *y,
+                                   const int *val);
+int gklt_lookahead_sync(gklt_lookahead *p);
+gklt_flist *gklt_lookahead_flist(gklt_lookahead *p);
+/* Index of the last frame the list has been tracked to (enqueued, not necessarily finished). */
+long gklt_lookahead_frames_tracked(gklt_lookahead *p);
 
 /* ---- memory helpers for callers that have no HIP of their own (no reference counterpart) ---- */
 
