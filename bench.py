@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--lookahead", type=int, default=16,
                     help="frames per gklt_lookahead_submit (0 = gklt_pipeline_step, frame at a time)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--main-only", action="store_true",
+                    help="timed + roofline legs only (for rocprofv3 runs: the frame-at-a-time and latency "
+                         "legs launch the same kernels with one frame per launch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     return ap.parse_args()
 
@@ -276,7 +279,9 @@ def main():
 
     # ---- frame at a time (gklt_pipeline_step): throughput, and synchronous per-frame latency
     # (what System::Track sees)
-    if B:
+    if a.main_only:
+        st1, k1, dt1, tracked1 = st, a.steps, dt, tracked
+    elif B:
         st.close()
         st1 = Stream(ctx, cfg, frames, seeds)
         st1.start()
@@ -292,12 +297,12 @@ def main():
     else:
         st1, k1, dt1, tracked1 = st, a.steps, dt, tracked
     lat = []
-    for _ in range(min(a.steps, 256)):
+    for _ in range(0 if a.main_only else min(a.steps, 256)):
         q0 = time.perf_counter()
         st1.step()
         st1.sync()
         lat.append((time.perf_counter() - q0) * 1e3)
-    lat = np.array(lat)
+    lat = np.array(lat if lat else [float("nan")])
 
     b_pyr, foot, px = algorithmic_bytes(cfg)
     per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}

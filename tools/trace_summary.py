@@ -16,9 +16,9 @@ def main(d, timeline=0):
     rows = list(csv.DictReader(open(f)))
     g = collections.defaultdict(list)
     for r in rows:
-        g[(short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r["VGPR_Count"], r["LDS_Block_Size"])].append(
+        g[(short(r["Kernel_Name"]), r["Grid_Size_X"], r["Grid_Size_Y"], r.get("Grid_Size_Z", "1"), r["LDS_Block_Size"])].append(
             int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    print("%-42s %8s %5s %5s %6s %6s %8s %8s %8s" % ("kernel", "gridX", "gridY", "vgpr", "lds", "calls", "med_us", "min_us", "max_us"))
+    print("%-42s %8s %5s %5s %6s %6s %8s %8s %8s" % ("kernel", "gridX", "gridY", "gridZ", "lds", "calls", "med_us", "min_us", "max_us"))
     for k, v in sorted(g.items()):
         v.sort()
         print("%-42s %8s %5s %5s %6s %6d %8.2f %8.2f %8.2f" % (k + (len(v), v[len(v) // 2] / 1e3, v[0] / 1e3, v[-1] / 1e3)))
