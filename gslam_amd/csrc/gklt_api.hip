@@ -67,6 +67,8 @@ static int ensure_nv(gklt_ctx *ctx, int n) {
   return 0;
 }
 
+int ensure_bearing_buffers(gklt_ctx *ctx, int n) { return ensure_nv(ctx, n); }
+
 static int check_params(const gklt_params &p) {
   if (p.nPyramidLevels < 1 || p.nPyramidLevels > GKLT_MAX_LEVELS) {
     set_error("nPyramidLevels %d outside [1,%d]", p.nPyramidLevels, GKLT_MAX_LEVELS);
@@ -128,6 +130,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   (void)hipFree(ctx->d_invk);
   (void)hipFree(ctx->d_norm);
   (void)hipFree(ctx->d_vec);
+  (void)hipFree(ctx->d_rot);
   (void)hipStreamDestroy(ctx->s_pyr);
   (void)hipStreamDestroy(ctx->s_trk);
   delete ctx;

@@ -62,6 +62,8 @@ struct gklt_ctx {
   double *d_invk = nullptr;  // 9 doubles
   double *d_norm = nullptr, *d_vec = nullptr;
   int d_nv_capacity = 0;
+  double *d_rot = nullptr;  // row rotations + invK of the rotate-and-normalise epilogue
+  int d_rot_capacity = 0;   // in doubles
   // profiling
   int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
@@ -141,6 +143,8 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
                         int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
                         double *d_vec, unsigned long long *stats, float *const *mirrors,
                         int mirror_stride);
+// bearing vectors (gklt_bearing.hip); grows ctx->d_norm / d_vec to n entries (gklt_api.hip)
+int ensure_bearing_buffers(gklt_ctx *ctx, int n);
 // all launches of one pyramid build on stream s (gklt_api.hip)
 int enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t *src,
                   int src_stride);

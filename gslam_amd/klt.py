@@ -383,6 +383,32 @@ class Pipeline:
             self.h = C.c_void_p()
 
 
+def rotate_normalize(ctx, x, y, val, grid_height, rotations, invK, norm=None, vec=None, flist=None):
+    """ImageGrids::rotateAndNormalizePoint over the tracked features (gklt_rotate_normalize, or
+    gklt_flist_rotate_normalize when `flist` is given).  Returns (norm, vec)."""
+    rot = np.ascontiguousarray(rotations, np.float64).reshape(-1, 9)
+    K = np.ascontiguousarray(invK, np.float64).reshape(9)
+    dp = C.POINTER(C.c_double)
+    if flist is not None:
+        n = len(flist)
+    else:
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        val = np.ascontiguousarray(val, np.int32)
+        n = len(x)
+    norm = np.zeros((n, 3)) if norm is None else np.array(norm, np.float64)
+    vec = np.zeros((n, 3)) if vec is None else np.array(vec, np.float64)
+    if flist is not None:
+        _check(lib().gklt_flist_rotate_normalize(ctx.h, flist.h, int(grid_height), len(rot),
+                                                 rot.ctypes.data_as(dp), K.ctypes.data_as(dp),
+                                                 norm.ctypes.data_as(dp), vec.ctypes.data_as(dp)))
+    else:
+        _check(lib().gklt_rotate_normalize(ctx.h, n, _fp(x), _fp(y), _ip(val), int(grid_height), len(rot),
+                                           rot.ctypes.data_as(dp), K.ctypes.data_as(dp),
+                                           norm.ctypes.data_as(dp), vec.ctypes.data_as(dp)))
+    return norm, vec
+
+
 class Lookahead:
     """gklt_lookahead: the frame loop with batches of frames handed over ahead of time."""
 

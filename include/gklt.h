@@ -175,6 +175,26 @@ int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *sumDxx, const
 int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *pyr, int mode, int variant,
                              gklt_flist *fl, int gridW, int gridH);
 
+/* ---- bearing vectors with per-row rotation ---- */
+
+/* ImageGrids::rotateAndNormalizePoint (ImageGrids.hpp:73-106) applied as NormalizeFrameInvoker
+ * does right after KLTTrackFeatures (System.cpp:246-267,539-540): for every feature with
+ * val == KLT_TRACKED, interpolate the row rotations R[h0], R[h0+1] of its row band
+ * (h0 = (int)(y / grid_height)), T = (a R[h0] + (1-a) R[h0+1])^T invK, d = T (x,y,1),
+ * norm = d / |d|, vec = norm / norm[2]; fp64 throughout.  rotations = nrot row-major 3x3
+ * matrices (System: nrot = frameHeight/20 + 1, grid_height = 20, System.cpp:351-356).  Entries
+ * of other features are left as they are.  A feature whose band has no lower vertex row
+ * (h0 + 1 >= nrot; the reference reads past `rotations` there) is left untouched as well.
+ * gklt_rotate_normalize takes the list from host arrays, gklt_flist_rotate_normalize from a
+ * device list (no list transfer); norm3 / vec3 are host arrays of 3*n doubles, written directly
+ * by the kernel when both are page-locked. */
+int gklt_rotate_normalize(gklt_ctx *ctx, int n, const float *x, const float *y, const int *val,
+                          int grid_height, int nrot, const double *rotations, const double *invK,
+                          double *norm3, double *vec3);
+int gklt_flist_rotate_normalize(gklt_ctx *ctx, gklt_flist *fl, int grid_height, int nrot,
+                                const double *rotations, const double *invK, double *norm3,
+                                double *vec3);
+
 /* ---- frame pipeline: PyramidBuffer (System.h:30-56) + the call pattern of System::Track ---- */
 
 /* A 3-deep ring of device pyramids plus a device feature list.  gklt_pipeline_step() does what

@@ -504,6 +504,46 @@ int ok_count_remaining(int n, const int *val) { /* LK.hpp:27-38 */
   return c;
 }
 
+/* ImageGrids.hpp:73-106 for every feature with val == KLT_TRACKED (System.cpp:246-267).
+ * The 3x3 arithmetic runs inside OpenCV in the reference (MatExpr a*A + b*B -> scaled add,
+ * gemm with transposed first operand, cv::norm L2, `dst *= s`): un-vendored, un-pinned ->
+ * PARITY UNPINNED for these steps.  Restated as plain fp64, unfused, sums left to right. */
+int ok_rotate_normalize(int n, const float *x, const float *y, const int *val, int grid_height,
+                        int nrot, const double *rotations, const double *invK, double *norm3,
+                        double *vec3) {
+  int i, k, r, c;
+  if (grid_height < 1 || nrot < 2) return -1;
+  for (i = 0; i < n; i++) {
+    int h0, h1;
+    double y0, y1, dist0, dist1, dist, M[9], T[9], d[3], nv, inv, nn[3];
+    const double *R0, *R1;
+    if (val[i] != 0) continue;                       /* System.cpp:250 */
+    h0 = (int)(y[i] / (float)grid_height);           /* :81 float / int */
+    h1 = h0 + 1;
+    if (h0 < 0 || h1 >= nrot) continue;              /* the reference indexes unchecked */
+    y0 = (double)(h0 * grid_height);                 /* originGridVertices[vIndex0].y */
+    y1 = (double)(h1 * grid_height);
+    dist0 = (double)y[i] - y0;                       /* :87-93 */
+    dist1 = y1 - (double)y[i];
+    dist = dist0 + dist1;
+    dist0 = dist1 / dist;
+    dist1 = 1.0 - dist0;
+    R0 = rotations + 9 * (size_t)h0;
+    R1 = rotations + 9 * (size_t)h1;
+    for (k = 0; k < 9; k++) M[k] = dist0 * R0[k] + dist1 * R1[k];          /* :94 */
+    for (r = 0; r < 3; r++)                                                /* :95 M^T * invK */
+      for (c = 0; c < 3; c++)
+        T[3 * r + c] = (M[r] * invK[c] + M[3 + r] * invK[3 + c]) + M[6 + r] * invK[6 + c];
+    for (r = 0; r < 3; r++)                                                /* :99-101 */
+      d[r] = (T[3 * r] * (double)x[i] + T[3 * r + 1] * (double)y[i]) + T[3 * r + 2];
+    nv = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);                  /* :102 */
+    inv = 1.0 / nv;                                                        /* :103 */
+    for (r = 0; r < 3; r++) { nn[r] = d[r] * inv; norm3[3 * (size_t)i + r] = nn[r]; }
+    for (r = 0; r < 3; r++) vec3[3 * (size_t)i + r] = nn[r] / nn[2];       /* System.cpp:260 */
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ selector */
 
 void ok_integral_products(const float *gx, const float *gy, int W, int H, float *sumxx,

@@ -91,6 +91,11 @@ int ok_track_features(ok_params *p, int W, int H, float *const *pyr1, float *con
                       double *vec3, int *iters_out);
 /* LK.hpp:27-38 */
 int ok_count_remaining(int n, const int *val);
+/* ImageGrids::rotateAndNormalizePoint + NormalizeFrameInvoker (ImageGrids.hpp:73-106,
+ * System.cpp:246-267): bearing vectors of the tracked features with per-row rotations. */
+int ok_rotate_normalize(int n, const float *x, const float *y, const int *val, int grid_height,
+                        int nrot, const double *rotations, const double *invK, double *norm3,
+                        double *vec3);
 
 /* System.cpp:385-392: gxx=gx*gx ... then cv::integral(.., CV_32F) -> (H+1)x(W+1) */
 void ok_integral_products(const float *gx, const float *gy, int W, int H, float *sumxx,

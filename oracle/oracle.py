@@ -199,6 +199,25 @@ def count_remaining(val):
     return lib().ok_count_remaining(len(val), _ip(val))
 
 
+def rotate_normalize(x, y, val, grid_height, rotations, invK, norm=None, vec=None):
+    """ImageGrids.hpp:73-106 on the tracked features; returns (norm, vec), n x 3 doubles."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    val = np.ascontiguousarray(val, np.int32)
+    rot = np.ascontiguousarray(rotations, np.float64).reshape(-1, 9)
+    K = np.ascontiguousarray(invK, np.float64).reshape(9)
+    n = len(x)
+    norm = np.zeros((n, 3)) if norm is None else np.array(norm, np.float64)
+    vec = np.zeros((n, 3)) if vec is None else np.array(vec, np.float64)
+    dp = C.POINTER(C.c_double)
+    rc = lib().ok_rotate_normalize(n, _fp(x), _fp(y), _ip(val), int(grid_height), len(rot),
+                                   rot.ctypes.data_as(dp), K.ctypes.data_as(dp),
+                                   norm.ctypes.data_as(dp), vec.ctypes.data_as(dp))
+    if rc:
+        raise RuntimeError("ok_rotate_normalize failed")
+    return norm, vec
+
+
 def integral_products(gx, gy):
     gx = np.ascontiguousarray(gx, np.float32)
     gy = np.ascontiguousarray(gy, np.float32)
