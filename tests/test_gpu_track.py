@@ -277,3 +277,50 @@ def test_pipeline_matches_oracle(klt, ok, gpu_ctx, pinned_out):
     assert tracked_total == total
     for a, b in zip(cur, prev):   # the "current" pyramid after the last step is frame nfr-1
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_build_and_track_from_two_host_threads(klt, ok, gpu_ctx):
+    """System.cpp:508-518: computePyramid(t+1) runs on a std::thread while KLTTrackFeatures works on
+    the other two ring buffers.  Same pattern through the C ABI (ctypes releases the GIL): one
+    thread builds, the caller tracks, 3-deep ring; results equal the sequential oracle."""
+    import threading
+    H, W, nfr, n = 180, 320, 8, 300
+    f = _stream(H, W, nfr, seed=33)
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    ring = [klt.Pyramid(gpu_ctx, W, H) for _ in range(3)]
+    got, errors = [], []
+
+    def preload(t):
+        try:
+            ring[t % 3].build(f[t])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    try:
+        ring[0].build(f[0])
+        ring[1].build(f[1])
+        cx, cy, cv = x, y, val
+        for t in range(1, nfr):
+            th = None
+            if t + 1 < nfr:
+                th = threading.Thread(target=preload, args=(t + 1,))
+                th.start()
+            cx, cy, cv = klt.KLTTrackFeatures(gpu_ctx, ring[(t - 1) % 3], ring[t % 3], cx, cy, cv)
+            got.append((cx, cy, cv))
+            if th:
+                th.join()
+        assert not errors
+    finally:
+        for p in ring:
+            p.close()
+    rx, ry, rv = x, y, val
+    prev = ok.compute_pyramid(op, f[0])
+    for t in range(1, nfr):
+        cur = ok.compute_pyramid(op, f[t])
+        rx, ry, rv = ok.track_features(op, prev, cur, rx, ry, rv)[:3]
+        _assert_same(got[t - 1], (rx, ry, rv))
+        prev = cur
