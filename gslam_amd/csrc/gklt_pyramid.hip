@@ -440,6 +440,8 @@ constexpr size_t fast_grad_lds() {
 // level 0 the halo pixels are smoothed from the reflected u8 window, which gives the same bits
 // as reflecting the smoothed plane because the taps are symmetric and each pair sum
 // (s[+j] + s[-j]) is commutative.  All passes are the register-blocked ones described above.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 template <int R0, int HI>
 struct LevelGeom {
   static constexpr int HIP = (HI + 3) / 4 * 4;    // halo of I padded to whole float4 groups
@@ -458,20 +460,33 @@ struct LevelGeom {
   static_assert(4 * NGA - 4 <= 2 * R0P && 60 + 4 * NGI <= AW, "row windows stay inside a row");
 };
 
+__device__ __forceinline__ int reflect101_near(int i, int n, bool wide) {
+  if (wide) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+  }
+  return reflect101(i, n);
+}
+
 // out[ROWS][WIDTH] <- src[reflect(ys + ty)][reflect(xs + tx)], every load issued before the
 // first LDS store.
 template <int ROWS, int WIDTH, typename SrcT>
 __device__ __forceinline__ void stage_region(const SrcT *__restrict__ src, int stride, int w, int h,
                                              int xs, int ys, float *out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index as a scalar: row indices, reflections and row pointers then live in SGPRs
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int PER = (ROWS + NW - 1) / NW;
-  const int sx0 = reflect101(xs + lane, w);
-  const int sx1 = reflect101(xs + 64 + min(lane, WIDTH - 65), w);
+  // Images of at least 192 px per side (uniform test): every staged index is less than one
+  // image size outside [0, n), so one reflection (two selects) suffices; smaller images take
+  // the general loop.
+  const bool wide = w >= 192 && h >= 192;
+  const int sx0 = reflect101_near(xs + lane, w, wide);
+  const int sx1 = reflect101_near(xs + 64 + min(lane, WIDTH - 65), w, wide);
   SrcT v0[PER], v1[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int ty = wave + i * NW;
-    const int sy = reflect101(ys + min(ty, ROWS - 1), h);
+    const int sy = reflect101_near(ys + min(ty, ROWS - 1), h, wide);
     const SrcT *row = src + (size_t)sy * stride;
     v0[i] = row[sx0];
     v1[i] = row[sx1];
@@ -518,7 +533,7 @@ __global__ __launch_bounds__(NT) void k_level(LevelIO io, int stride, int w, int
   float *I = lds;                        // IHh x AW
   float *scratch = I + G::IHh * G::AW;   // level-0 phase: S, A; afterwards: rowd, rowg, rowp
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   if constexpr (R0 > 0) {
     float *S = scratch;               // SH x SW source window
@@ -603,7 +618,10 @@ __global__ __launch_bounds__(NT) void k_level(LevelIO io, int stride, int w, int
       const float gy = corr_win<RG, -1>(vg, RG + j, d);
       const float ic = I[(4 * wave + j + HI) * G::AW + G::HIP + lane];
       if (x < w && y < h) {
-        tex[(size_t)y * w + x] = make_float4(ic, gx, gy, 0.0f);
+        // streaming store: the texels are next read by a tracker launch at least one build
+        // later, and must not evict the window footprints a concurrent tracker gathers from L2
+        const v4f t = {ic, gx, gy, 0.0f};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(tex + (size_t)y * w + x));
         if (img_out) img_out[(size_t)y * w + x] = ic;
       }
     }

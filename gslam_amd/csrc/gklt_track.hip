@@ -363,7 +363,9 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // footprint texel) into LDS and the four bilinear taps of every element are read from there,
 // instead of four gathers per element.
 // FPL = footprint texels per lane (0 = no staging).
-template <int EPL, int FPL>
+// NEC = elements per AVX-lane chain when known at compile time (7x7: 7, 11x11: 16, 21x21: 56;
+// 0 = run time): the chain sums then unroll into NEC reads followed by NEC ordered adds.
+template <int EPL, int FPL, int NEC = 0>
 __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
                                                 float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
@@ -372,11 +374,14 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
                                                 double *__restrict__ vec3,
                                                 unsigned long long *__restrict__ stats) {
   extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40] | fp[NF] (float4)
+  // A feature's chain is serial and latency bound; the pyramid kernels it shares the SIMDs with
+  // are throughput bound.  Raised wave priority lets the chain issue as soon as it is ready.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int f = blockIdx.x;
   const int ww = a.ww, wh = a.wh, npix = ww * wh;
   const int NA = SL * ((npix + SL) / SL);  // alignedPatchSize (LK.hpp:448)
-  const int nec = NA / SL;                 // elements per AVX-lane chain
+  const int nec = NEC > 0 ? NEC : NA / SL;  // elements per AVX-lane chain
   const int hw = ww / 2, hh = wh / 2;
   constexpr bool STAGE = FPL > 0;
   constexpr int FP = STAGE ? FPL : 1;
@@ -437,14 +442,22 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
       const int q = lane >> 3, k = lane & 7;
       const float *p = prod + q * NA + k;
       float acc = 0.f;
-      // groups of 8 independent LDS reads (clamped index), then the adds in element order
-      for (int j0 = 0; j0 < nec; j0 += 8) {
-        float t[8];
+      if constexpr (NEC > 0 && NEC <= 16) {
+        float t[NEC];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = p[min(j0 + u, nec - 1) * SL];
+        for (int u = 0; u < NEC; ++u) t[u] = p[u * SL];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (j0 + u < nec) acc = acc + t[u];
+        for (int u = 0; u < NEC; ++u) acc = acc + t[u];
+      } else {
+        // groups of 8 independent LDS reads (clamped index), then the adds in element order
+        for (int j0 = 0; j0 < nec; j0 += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = p[min(j0 + u, nec - 1) * SL];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j0 + u < nec) acc = acc + t[u];
+        }
       }
       part[lane] = acc;
     }
@@ -728,9 +741,16 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
 #define GKLT_TRACK_W(E, FP)                                                                    \
   hipLaunchKernelGGL((k_track_w<E, FP>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,       \
                      d_norm, d_vec, stats)
+    const int nec = NA / 8;
     if (!stage) {
-      if (epl <= 1) GKLT_TRACK_W(1, 0);
-      else if (epl <= 2) GKLT_TRACK_W(2, 0);
+      if (epl <= 1 && nec == 7) {  // 7x7
+        hipLaunchKernelGGL((k_track_w<1, 0, 7>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,
+                           d_norm, d_vec, stats);
+      } else if (epl <= 1) GKLT_TRACK_W(1, 0);
+      else if (epl <= 2 && nec == 16) {  // 11x11
+        hipLaunchKernelGGL((k_track_w<2, 0, 16>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,
+                           d_norm, d_vec, stats);
+      } else if (epl <= 2) GKLT_TRACK_W(2, 0);
       else if (epl <= 4) GKLT_TRACK_W(4, 0);
       else if (epl <= 8) GKLT_TRACK_W(8, 0);
       else GKLT_TRACK_W(16, 0);
