@@ -36,9 +36,16 @@ klt.lib()  # load libgklt.so (and the system HIP runtime) before anything can im
 
 RESEED_EVERY = 32
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# HBM bytes per single-frame launch measured with rocprofv3 --pmc (TCC_EA0_RDREQ*/WRREQ* passes,
-# profiles/r01_c2_pmc_by_kernel.txt); None where no PMC pass has been committed.
-PMC_TRAFFIC = {("C2", "track"): 21.6e6 + 1.0e6}
+# HBM bytes per FRAME of a launch, from the rocprofv3 --pmc passes committed under profiles/
+# (r01_c2_lookahead16_pmc_by_kernel.txt: FETCH_SIZE and WRITE_SIZE in separate passes, KiB per
+# 16-frame launch).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B,
+# so reads are doubled; WRITE_SIZE is exact.  None where no PMC pass has been committed.
+def _pmc_bytes(fetch_kib, write_kib, frames):
+    return (2.0 * fetch_kib + write_kib) * 1024.0 / frames
+
+
+PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(302800.0, 6794.0, 16),
+               ("C2", "level0"): _pmc_bytes(90890.0, 550800.0, 16)}
 
 
 def parse():
@@ -319,8 +326,7 @@ def main():
     avg_s = per_kernel[dom]["avg_us"] * 1e-6
     alg = alg_by_kernel[dom]
     achieved = alg / avg_s / 1e9
-    # HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (TCC_EA0 read +
-    # write requests, gfx950 units as in MI355X_MICROARCH.md); measured at one frame per launch.
+    # HBM bytes per frame from the rocprofv3 PMC passes committed under profiles/ (see PMC_TRAFFIC)
     pmc_traffic = PMC_TRAFFIC.get((a.config, dom))
 
     names = {"track": "k_track_w", "level0": "k_level<u8>"}
@@ -361,8 +367,9 @@ def main():
                      "note": "dominant kernel by total time in the profiled leg; tracker bytes = "
                              "[4*N*L + 3*iters] footprints of (w+1)(h+1)*4 B per frame "
                              "(iters/feature/frame=%.2f), level-0 bytes = W*H*(1+12+1) per frame; "
-                             "traffic = PMC bytes/launch from profiles/ (separate rocprofv3 --pmc "
-                             "passes) scaled by frames_per_launch; see DESIGN.md 4" % (p_iters / psteps / n)},
+                             "traffic = (2*FETCH_SIZE + WRITE_SIZE) per frame from the rocprofv3 --pmc passes "
+                             "in profiles/r01_c2_lookahead16_pmc_by_kernel.txt (16-frame launches) x "
+                             "frames_per_launch; see DESIGN.md 4" % (p_iters / psteps / n)},
         "kernels": per_kernel,
         "pyramid_algorithmic_bytes_per_frame": b_pyr,
     }
