@@ -29,52 +29,75 @@ namespace {
 constexpr unsigned kAccepted = 0x80000000u;
 
 // ------------------------------------------------------------------ S6 integral images
-// One wave per 64 rows.  Texels of a 64x64 tile are read row-contiguously, the products are
-// transposed through LDS (stride 65: conflict-free both ways), each lane extends the running
-// prefix of its row over 64 columns, and the prefixes are written back row-contiguously.
-__global__ __launch_bounds__(64) void k_integral_rows(const Texel *__restrict__ tex, int w, int h,
-                                                      float *__restrict__ sxx,
-                                                      float *__restrict__ syy,
-                                                      float *__restrict__ sxy) {
+// The running prefix of a row (and then of a column) is one serial fp32 chain: cv::integral's
+// order has to be kept because the scores are differences of sums ~1e9.  The parallelism is
+// rows x 3 quantities (then columns x 3), so the kernels are built around keeping those chains
+// fed: the loads of the next tile are in flight while the chains of the current one run.
+//
+// Rows: a block of 4 waves owns 64 rows.  Per 64-column tile every wave loads 16 rows
+// row-contiguously (16 loads in flight per lane, issued one tile ahead), the products are
+// transposed through LDS (stride 65: conflict-free both ways), wave q < 3 extends the running
+// prefixes of quantity q (lane = row), and all waves write the prefixes back row-contiguously.
+__global__ __launch_bounds__(256) void k_integral_rows(const Texel *__restrict__ tex, int w, int h,
+                                                       float *__restrict__ sxx,
+                                                       float *__restrict__ syy,
+                                                       float *__restrict__ sxy) {
   __shared__ float t[3][64][65];
-  const int lane = threadIdx.x, y0 = blockIdx.x * 64, w1 = w + 1;
-  float rxx = 0.f, ryy = 0.f, rxy = 0.f;  // running prefix of row y0+lane
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int y0 = blockIdx.x * 64, w1 = w + 1, r0 = 16 * wave;
+  float run = 0.f;  // waves 0..2: running prefix of quantity `wave`, row y0 + lane
+  float gx[16], gy[16];
+  auto load = [&](int x0) {
+    const int col = min(x0 + lane, w - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // clamped, unconditional: all 16 loads are in flight together
+      const Texel v = tex[(size_t)min(y0 + r0 + r, h - 1) * w + col];
+      gx[r] = v.y;
+      gy[r] = v.z;
+    }
+  };
+  load(0);
   for (int x0 = 0; x0 < w; x0 += 64) {
     const int x = x0 + lane;
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) {
-      // clamped, unconditional load (keeps the 8 loads of an unrolled group in flight)
-      const Texel v = tex[(size_t)min(y0 + r, h - 1) * w + min(x, w - 1)];
-      const bool in = x < w && y0 + r < h;
-      const float a = in ? v.y : 0.f, b = in ? v.z : 0.f;
-      t[0][r][lane] = a * a;  // cv::multiply, System.cpp:386-388
-      t[1][r][lane] = b * b;
-      t[2][r][lane] = a * b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool in = x < w && y0 + r0 + r < h;
+      const float a = in ? gx[r] : 0.f, b = in ? gy[r] : 0.f;
+      t[0][r0 + r][lane] = a * a;  // cv::multiply, System.cpp:386-388
+      t[1][r0 + r][lane] = b * b;
+      t[2][r0 + r][lane] = a * b;
     }
     __syncthreads();
-    const int nc = min(64, w - x0);
-    for (int c = 0; c < nc; ++c) {
-      rxx = rxx + t[0][lane][c]; t[0][lane][c] = rxx;
-      ryy = ryy + t[1][lane][c]; t[1][lane][c] = ryy;
-      rxy = rxy + t[2][lane][c]; t[2][lane][c] = rxy;
+    if (x0 + 64 < w) load(x0 + 64);
+    if (wave < 3) {
+      float(*tq)[65] = t[wave];
+      const int nc = min(64, w - x0);
+#pragma unroll 8
+      for (int c = 0; c < nc; ++c) {
+        run = run + tq[lane][c];
+        tq[lane][c] = run;
+      }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < 64; ++r) {
-      if (x < w && y0 + r < h) {
-        const size_t o = (size_t)(y0 + r + 1) * w1 + x + 1;
-        sxx[o] = t[0][r][lane];
-        syy[o] = t[1][r][lane];
-        sxy[o] = t[2][r][lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (x < w && y0 + r0 + r < h) {
+        const size_t o = (size_t)(y0 + r0 + r + 1) * w1 + x + 1;
+        sxx[o] = t[0][r0 + r][lane];
+        syy[o] = t[1][r0 + r][lane];
+        sxy[o] = t[2][r0 + r][lane];
       }
     }
     __syncthreads();
   }
 }
 
-// sum(y+1, x+1) = sum(y, x+1) + prefix_y(x), in place; row 0 and column 0 are zero.
-__global__ void k_integral_cols(float *__restrict__ sxx, float *__restrict__ syy,
-                                float *__restrict__ sxy, int w, int h) {
+// sum(y+1, x+1) = sum(y, x+1) + prefix_y(x), in place; row 0 and column 0 are zero.  One thread
+// per column and quantity; rows are taken in groups of 32 with the next group's loads issued
+// before the current group's chain of adds.
+__global__ __launch_bounds__(64) void k_integral_cols(float *__restrict__ sxx,
+                                                      float *__restrict__ syy,
+                                                      float *__restrict__ sxy, int w, int h) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x;  // 0..w (column of the (h+1)x(w+1) image)
   const int w1 = w + 1;
   if (x > w) return;
@@ -84,11 +107,25 @@ __global__ void k_integral_cols(float *__restrict__ sxx, float *__restrict__ syy
     for (int y = 1; y <= h; ++y) s[(size_t)y * w1] = 0.f;
     return;
   }
+  constexpr int G = 32;
+  float cur[G], nxt[G];
+#pragma unroll
+  for (int i = 0; i < G; ++i) cur[i] = s[(size_t)min(1 + i, h) * w1 + x];
   float acc = 0.f;
-#pragma unroll 8
-  for (int y = 1; y <= h; ++y) {
-    acc = acc + s[(size_t)y * w1 + x];
-    s[(size_t)y * w1 + x] = acc;
+  for (int yb = 1; yb <= h; yb += G) {
+    if (yb + G <= h) {
+#pragma unroll
+      for (int i = 0; i < G; ++i) nxt[i] = s[(size_t)min(yb + G + i, h) * w1 + x];
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      if (yb + i <= h) {
+        acc = acc + cur[i];
+        s[(size_t)(yb + i) * w1 + x] = acc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) cur[i] = nxt[i];
   }
 }
 
@@ -363,9 +400,9 @@ int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyram
   const int w = py->lv[0].w, h = py->lv[0].h;
   {
     ProfScope ps(ctx, s, GKLT_K_INTEGRAL);
-    hipLaunchKernelGGL(k_integral_rows, dim3((h + 63) / 64), dim3(64), 0, s, py->lv[0].tex, w, h,
+    hipLaunchKernelGGL(k_integral_rows, dim3((h + 63) / 64), dim3(256), 0, s, py->lv[0].tex, w, h,
                        sc->sum[0], sc->sum[1], sc->sum[2]);
-    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 255) / 256, 3), dim3(256), 0, s, sc->sum[0],
+    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(64), 0, s, sc->sum[0],
                        sc->sum[1], sc->sum[2], w, h);
   }
   GKLT_HIP(hipGetLastError());
