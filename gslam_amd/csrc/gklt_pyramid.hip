@@ -789,11 +789,11 @@ int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const LevelIO &
 }  // namespace
 
 // Radii the fused level kernel is instantiated for: grad_sigma = 1.0 (R 3), pyramid sigma 1.8
-// (subsampling 2 * 0.9, R 5), level-0 smoothing radius 1..4 (windows up to 19 px).
+// (subsampling 2 * 0.9, R 5), level-0 smoothing radius 1..6 (windows up to 29 px; the as-shipped 21x21 has radius 6).
 bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d) {
   if (g.r != 3 || d.r != 3) return false;
   if (pyr && pyr->r != 5) return false;
-  if (s0 && (s0->r < 1 || s0->r > 4)) return false;
+  if (s0 && (s0->r < 1 || s0->r > 6)) return false;
   return true;
 }
 
@@ -834,6 +834,8 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
     GKLT_LEVEL_CASE(2)
     GKLT_LEVEL_CASE(3)
     GKLT_LEVEL_CASE(4)
+    GKLT_LEVEL_CASE(5)
+    GKLT_LEVEL_CASE(6)
   }
 #undef GKLT_LEVEL_CASE
   set_error("fused level kernel: unsupported level-0 radius %d", s0.r);
