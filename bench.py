@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=64, help="distinct synthetic frames (looped)")
     ap.add_argument("--lookahead", type=int, default=16,
                     help="frames per gklt_lookahead_submit (0 = gklt_pipeline_step, frame at a time)")
+    ap.add_argument("--track-waves", type=int, default=0, help="wavefronts per tracker launch (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--main-only", action="store_true",
                     help="timed + roofline legs only (for rocprofv3 runs: the frame-at-a-time and latency "
@@ -243,6 +244,7 @@ def main():
     params_kw = dict(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
     gp = klt.make_params(**params_kw)
     ctx = klt.Context(local_rank, gp)
+    ctx.set_track_waves(a.track_waves)
 
     seed = rank_seed(rank)
     frames = synth.make_stream(H, W, a.frames, seed=seed)

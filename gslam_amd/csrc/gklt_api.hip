@@ -686,6 +686,13 @@ extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   return 0;
 }
 
+// wavefronts of a wave-per-feature tracker launch (0 = default cap of 3072)
+extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
+  if (!ctx || waves < 0) return GKLT_EINVAL;
+  ctx->track_waves = waves;
+  return 0;
+}
+
 // 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels
 extern "C" int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;

@@ -66,6 +66,7 @@ struct gklt_ctx {
   int d_rot_capacity = 0;   // in doubles
   // profiling
   int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
+  int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;
   struct Span {

@@ -17,6 +17,8 @@
 //      acceptances, i.e. it keeps the nFeatures highest-priority members of that set:
 //      k_rank_assign ranks the accepted set and writes slot[rank].
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -801,8 +803,11 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
                             sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
-    for (int k = first; k < round; ++k)
+    for (int k = first; k < round; ++k) {
+      if (getenv("GKLT_SELECT_TRACE"))
+        fprintf(stderr, "uni round %d caps %d left %u\n", k, caps.enabled, sc->h_counters[k]);
       if (sc->h_counters[k] == 0) done = true;
+    }
     if (!done && round > kMaxRounds) {
       set_error("uniform selection did not converge in %d rounds", kMaxRounds);
       return GKLT_EHIP;

@@ -374,11 +374,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
                                                 double *__restrict__ vec3,
                                                 unsigned long long *__restrict__ stats) {
   extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40] | fp[NF] (float4)
-  // A feature's chain is serial and latency bound; the pyramid kernels it shares the SIMDs with
-  // are throughput bound.  Raised wave priority lets the chain issue as soon as it is ready.
-  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
-  const int f = blockIdx.x;
   const int ww = a.ww, wh = a.wh, npix = ww * wh;
   const int NA = SL * ((npix + SL) / SL);  // alignedPatchSize (LK.hpp:448)
   const int nec = NEC > 0 ? NEC : NA / SL;  // elements per AVX-lane chain
@@ -390,9 +386,6 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
   float4 *fp = reinterpret_cast<float4 *>(part + 40);
   const int FW = ww + 1, NF = FW * (wh + 1);
 
-  const int val0 = fval[f];
-  float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
-  int vcur = val0;
   // element -> texel offset inside the window (tail elements clamp to the last pixel, value 0)
   int eoff_x[EPL], eoff_y[EPL];
   bool evalid[EPL];
@@ -473,6 +466,13 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
       tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), q));
   };
 
+  // The grid is capped (launch_track_frames) so that a launch never takes every wave slot of
+  // the chip away from the pyramid build it overlaps with; a wavefront then takes features
+  // blockIdx.x, blockIdx.x + gridDim.x, ...
+  for (int f = blockIdx.x; f < a.n; f += gridDim.x) {
+  const int val0 = fval[f];
+  float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
+  int vcur = val0;
   int iters_total = 0, ntracked = 0;
   for (int fr = 0; fr < F.nframes; ++fr) {
   if (vcur < 0) {  // LK.hpp:830: lost features are not touched
@@ -664,6 +664,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
       atomicAdd(&sh[1], (unsigned long long)iters_total);
     }
   }
+  }  // features of this wavefront
 }
 
 }  // namespace
@@ -732,6 +733,12 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
     }
     for (int l = 0; l < P.nPyramidLevels; ++l)
       a.lv[l] = TrackLevel{nullptr, nullptr, py[0]->lv[l].w, py[0]->lv[l].h};
+    // Default cap: 3 wavefronts per SIMD (256 CUs x 4 SIMDs).  A launch that takes more of the
+    // chip's wave slots starves the pyramid build it overlaps with (measured at C2, lookahead 16:
+    // 3072 -> 160 M, 3584 -> 150 M, 4000 -> 141 M feature-frames/s; at C3 the uncapped 16000
+    // wavefronts serialise the two kernels).
+    // Single-frame launches are short and latency matters: one wavefront per feature.
+    const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? 3072 : n));
     TrackFrames F{};
     F.nframes = nframes;
     for (int j = 0; j <= nframes; ++j)
@@ -739,16 +746,16 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
     for (int j = 0; j < nframes; ++j) F.mirror[j] = mirrors ? mirrors[j] : nullptr;
     ProfScope ps(ctx, s, GKLT_K_TRACK);
 #define GKLT_TRACK_W(E, FP)                                                                    \
-  hipLaunchKernelGGL((k_track_w<E, FP>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,       \
+  hipLaunchKernelGGL((k_track_w<E, FP>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,  \
                      d_norm, d_vec, stats)
     const int nec = NA / 8;
     if (!stage) {
       if (epl <= 1 && nec == 7) {  // 7x7
-        hipLaunchKernelGGL((k_track_w<1, 0, 7>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,
+        hipLaunchKernelGGL((k_track_w<1, 0, 7>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,
                            d_norm, d_vec, stats);
       } else if (epl <= 1) GKLT_TRACK_W(1, 0);
       else if (epl <= 2 && nec == 16) {  // 11x11
-        hipLaunchKernelGGL((k_track_w<2, 0, 16>), dim3(n), block, wlds, s, a, F, x, y, val, d_invk,
+        hipLaunchKernelGGL((k_track_w<2, 0, 16>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,
                            d_norm, d_vec, stats);
       } else if (epl <= 2) GKLT_TRACK_W(2, 0);
       else if (epl <= 4) GKLT_TRACK_W(4, 0);

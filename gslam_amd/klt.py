@@ -159,6 +159,10 @@ class Context:
         """0 = one feature per wavefront (default), 1 = one feature per 8-lane slice."""
         _check(lib().gklt_ctx_set_track_impl(self.h, int(impl)))
 
+    def set_track_waves(self, waves):
+        """wavefronts per tracker launch (0 = default cap of 3072)"""
+        _check(lib().gklt_ctx_set_track_waves(self.h, int(waves)))
+
     def set_pyramid_impl(self, impl):
         """0 = fused level kernels when the radii allow (default), 1 = separate kernels."""
         _check(lib().gklt_ctx_set_pyramid_impl(self.h, int(impl)))
