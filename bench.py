@@ -209,6 +209,17 @@ def cpu_baseline(params_kw, frames, seeds, nframes, threads):
     return tracked / dt, dt
 
 
+def latency_leg(st, n):
+    """synchronous per-frame latency of gklt_pipeline_step, ms"""
+    lat = []
+    for _ in range(n):
+        q0 = time.perf_counter()
+        st.step()
+        st.sync()
+        lat.append((time.perf_counter() - q0) * 1e3)
+    return lat
+
+
 def reduce_over_ranks(dist, dt, tracked, iters):
     """max wall time, summed counts (CPU tensors: works on gloo and needs no GPU)."""
     if dist is None:
@@ -252,6 +263,32 @@ def main():
     seeds = (sx, sy, np.zeros(len(sx), np.int32))
 
     B = a.lookahead
+
+    def barrier():
+        ctx.device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- frame at a time (gklt_pipeline_step): throughput, and synchronous per-frame latency
+    # (what System::Track sees).  Runs first, on its own 3-pyramid ring; secondary numbers.
+    fa1 = None
+    lat = [float("nan")]
+    if B and not a.main_only:
+        st1 = Stream(ctx, cfg, frames, seeds)
+        st1.start()
+        st1.run(a.warmup)
+        st1.sync()
+        st1.fl.stats(reset=True)
+        k1 = min(a.steps, 1024)
+        q0 = time.perf_counter()
+        st1.run(k1)
+        st1.sync()
+        dt1 = time.perf_counter() - q0
+        tracked1, _ = st1.fl.stats(reset=True)
+        fa1 = (tracked1, dt1, k1)
+        lat = latency_leg(st1, min(a.steps, 256))
+        st1.close()
+
     if B:
         st = LookaheadStream(ctx, cfg, frames, seeds, B)
     else:
@@ -260,11 +297,6 @@ def main():
     st.run(a.warmup)
     st.sync()
     st.fl.stats(reset=True)
-
-    def barrier():
-        ctx.device_synchronize()
-        if dist is not None:
-            dist.barrier()
 
     barrier()
     t0 = time.perf_counter()
@@ -286,32 +318,14 @@ def main():
     ctx.profile_enable(False)
     p_tracked, p_iters = st.fl.stats(reset=True)
 
-    # ---- frame at a time (gklt_pipeline_step): throughput, and synchronous per-frame latency
-    # (what System::Track sees)
-    if a.main_only:
-        st1, k1, dt1, tracked1 = st, a.steps, dt, tracked
-    elif B:
-        st.close()
-        st1 = Stream(ctx, cfg, frames, seeds)
-        st1.start()
-        st1.run(a.warmup)
-        st1.sync()
-        st1.fl.stats(reset=True)
-        k1 = min(a.steps, 1024)
-        q0 = time.perf_counter()
-        st1.run(k1)
-        st1.sync()
-        dt1 = time.perf_counter() - q0
-        tracked1, _ = st1.fl.stats(reset=True)
-    else:
-        st1, k1, dt1, tracked1 = st, a.steps, dt, tracked
-    lat = []
-    for _ in range(0 if a.main_only else min(a.steps, 256)):
-        q0 = time.perf_counter()
-        st1.step()
-        st1.sync()
-        lat.append((time.perf_counter() - q0) * 1e3)
-    lat = np.array(lat if lat else [float("nan")])
+    if not B:
+        fa1 = (tracked, dt, a.steps)
+        if not a.main_only:
+            lat = latency_leg(st, min(a.steps, 256))
+    elif fa1 is None:
+        fa1 = (float("nan"), 1.0, 1)
+    tracked1, dt1, k1 = fa1
+    lat = np.array(lat)
 
     b_pyr, foot, px = algorithmic_bytes(cfg)
     per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}
@@ -384,7 +398,7 @@ def main():
                                "kind": "port",
                                "sample": "%d frames of the same stream (pyramid + track), oracle/ C "
                                          "restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
-    st1.close()
+    st.close()
     ctx.close()
     if rank == 0:
         print(json.dumps(out))
