@@ -17,8 +17,6 @@
 //      acceptances, i.e. it keeps the nFeatures highest-priority members of that set:
 //      k_rank_assign ranks the accepted set and writes slot[rank].
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -250,17 +248,84 @@ __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, 
   if (left) atomicAdd(&counters[round], (unsigned)left);
 }
 
-// accepted pixels -> key list (order irrelevant, ranked later)
-__global__ void k_collect(const unsigned *__restrict__ state, int w, int h,
-                          unsigned long long *__restrict__ list, unsigned *__restrict__ count,
-                          unsigned cap) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const unsigned s = state[(size_t)y * w + x];
-  if (s & kAccepted) {
-    const unsigned i = atomicAdd(count, 1u);
-    if (i < cap) list[i] = prio_key(s & ~kAccepted, x, y);
+// Appends the accepted pixels of a 256-column x 32-row block to a list, emit(i, x, y, score)
+// writing entry i.  ONE global atomic per block: accepted pixels are at least mindist apart, so
+// per-pixel (or per-wave) atomics on the single counter serialise (10^4 of them cost ~100 us).
+constexpr int kCollectRows = 32;
+inline dim3 collect_grid(int w, int h) {
+  return dim3((w + 255) / 256, (h + kCollectRows - 1) / kCollectRows);
+}
+template <typename Emit>
+__device__ __forceinline__ void collect_block(const unsigned *__restrict__ state, int w, int h,
+                                              unsigned *__restrict__ count, unsigned cap,
+                                              Emit emit) {
+  __shared__ unsigned wtot[4];
+  __shared__ unsigned base;
+  const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * kCollectRows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned mask = 0;  // bit r: pixel (x, y0 + r) is accepted
+  if (x < w) {
+#pragma unroll 8
+    for (int r = 0; r < kCollectRows; ++r) {
+      const int y = min(y0 + r, h - 1);
+      const unsigned s = state[(size_t)y * w + x];
+      if (y0 + r < h && (s & kAccepted)) mask |= 1u << r;
+    }
   }
+  const unsigned c = __popc(mask);
+  unsigned inc = c;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned t = __shfl_up(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  unsigned off = inc - c;
+  for (int k = 0; k < wave; ++k) off += wtot[k];
+  if (threadIdx.x == 0) {
+    const unsigned total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    base = total ? atomicAdd(count, total) : 0u;
+  }
+  __syncthreads();
+  unsigned i = base + off;
+  while (mask) {
+    const int r = __ffs(mask) - 1;
+    mask &= mask - 1;
+    if (i < cap) emit(i, x, y0 + r, state[(size_t)(y0 + r) * w + x] & ~kAccepted);
+    ++i;
+  }
+}
+
+// accepted pixels -> key list (order irrelevant, ranked later)
+__global__ __launch_bounds__(256) void k_collect(const unsigned *__restrict__ state, int w, int h,
+                                                 unsigned long long *__restrict__ list,
+                                                 unsigned *__restrict__ count, unsigned cap) {
+  collect_block(state, w, h, count, cap,
+                [&](unsigned i, int x, int y, unsigned s) { list[i] = prio_key(s, x, y); });
+}
+
+// rank[i] += number of keys of slice blockIdx.y that are greater than keys[i] (rank zeroed
+// before the launch).  The key range is split over gridDim.y so that ranking ~10^4 accepted
+// features is spread over the whole chip instead of 40 workgroups.
+constexpr int kRankSlices = 16;
+__global__ __launch_bounds__(256) void k_rank_partial(const unsigned long long *__restrict__ keys,
+                                                      unsigned n, unsigned *__restrict__ rank) {
+  __shared__ unsigned long long tile[256];
+  const unsigned i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long own = i < n ? keys[i] : 0ull;
+  const unsigned per = ((n + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
+  const unsigned jb = blockIdx.y * per, je = min(n, jb + per);
+  unsigned rk = 0;
+  for (unsigned j0 = jb; j0 < je; j0 += 256) {
+    tile[threadIdx.x] = j0 + threadIdx.x < je ? keys[j0 + threadIdx.x] : 0ull;
+    __syncthreads();
+    const unsigned m = min(256u, je - j0);
+#pragma unroll 8
+    for (unsigned j = 0; j < m; ++j) rk += tile[j] > own;
+    __syncthreads();
+  }
+  if (i < n && rk) atomicAdd(&rank[i], rk);
 }
 
 // slots to fill, in list order: every slot (selecting all) or the lost ones (replacing)
@@ -294,26 +359,17 @@ __global__ void k_lost_slots(const int *__restrict__ fval, int n, int overwrite,
 }
 
 // rank of each accepted key among all accepted keys (descending); rank < nslots -> slot[rank]
-__global__ __launch_bounds__(256) void k_rank_assign(const unsigned long long *__restrict__ list,
-                                                     const unsigned *__restrict__ count,
-                                                     unsigned cap, const int *__restrict__ slots,
-                                                     const int *__restrict__ nslots,
-                                                     float *__restrict__ fx,
-                                                     float *__restrict__ fy,
-                                                     int *__restrict__ fval) {
-  __shared__ unsigned long long tile[256];
-  const unsigned n = min(*count, cap);
+__global__ __launch_bounds__(256) void k_assign(const unsigned long long *__restrict__ list,
+                                                const unsigned *__restrict__ ranks, unsigned n,
+                                                const int *__restrict__ slots,
+                                                const int *__restrict__ nslots,
+                                                float *__restrict__ fx, float *__restrict__ fy,
+                                                int *__restrict__ fval) {
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long own = i < n ? list[i] : 0ull;
-  unsigned rank = 0;
-  for (unsigned j0 = 0; j0 < n; j0 += 256) {
-    tile[threadIdx.x] = j0 + threadIdx.x < n ? list[j0 + threadIdx.x] : 0ull;
-    __syncthreads();
-    const unsigned m = min(256u, n - j0);
-    for (unsigned j = 0; j < m; ++j) rank += tile[j] > own;
-    __syncthreads();
-  }
-  if (i < n && (int)rank < *nslots) {
+  if (i >= n) return;
+  const unsigned long long own = list[i];
+  const unsigned rank = ranks[i];
+  if ((int)rank < *nslots) {
     const int s = slots[rank];
     fx[s] = (float)(0xFFFF - (int)(own & 0xFFFF));
     fy[s] = (float)(0xFFFF - (int)((own >> 16) & 0xFFFF));
@@ -345,6 +401,7 @@ struct SelScratch {
   unsigned *state = nullptr;
   unsigned char *blocked = nullptr;
   unsigned long long *list = nullptr;
+  unsigned *rank = nullptr;      // rank of list[i] among the accepted keys
   unsigned *counters = nullptr;  // [0] accepted count, [1..] per-round undecided
   int *slots = nullptr, *nslots = nullptr;
   unsigned *h_counters = nullptr;  // pinned
@@ -361,6 +418,7 @@ void sel_free(SelScratch *s) {
   (void)hipFree(s->state);
   (void)hipFree(s->blocked);
   (void)hipFree(s->list);
+  (void)hipFree(s->rank);
   (void)hipFree(s->counters);
   (void)hipFree(s->slots);
   (void)hipFree(s->nslots);
@@ -388,6 +446,7 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
     GKLT_HIP(hipMalloc(&s->state, sizeof(unsigned) * (size_t)w * h));
     GKLT_HIP(hipMalloc(&s->blocked, (size_t)w * h));
     GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * (size_t)s->cap_list));
+    GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * (size_t)s->cap_list));
     GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
     GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
     GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
@@ -481,8 +540,8 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   }
   {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    hipLaunchKernelGGL(k_collect, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->state, w, h,
-                       sc->list, sc->counters, (unsigned)sc->cap_list);
+    hipLaunchKernelGGL(k_collect, collect_grid(w, h), dim3(256), 0, s, sc->state, w, h, sc->list,
+                       sc->counters, (unsigned)sc->cap_list);
   }
   GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned), hipMemcpyDeviceToHost, s));
   GKLT_HIP(hipStreamSynchronize(s));
@@ -493,9 +552,14 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   }
   {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    if (naccepted > 0)
-      hipLaunchKernelGGL(k_rank_assign, dim3((naccepted + 255) / 256), dim3(256), 0, s, sc->list,
-                         sc->counters, (unsigned)sc->cap_list, sc->slots, sc->nslots, fx, fy, fval);
+    if (naccepted > 0) {
+      const unsigned nb = (naccepted + 255) / 256;
+      GKLT_HIP(hipMemsetAsync(sc->rank, 0, sizeof(unsigned) * naccepted, s));
+      hipLaunchKernelGGL(k_rank_partial, dim3(nb, kRankSlices), dim3(256), 0, s, sc->list,
+                         naccepted, sc->rank);
+      hipLaunchKernelGGL(k_assign, dim3(nb), dim3(256), 0, s, sc->list, sc->rank, naccepted,
+                         sc->slots, sc->nslots, fx, fy, fval);
+    }
     if (n > 0)
       hipLaunchKernelGGL(k_fill_rest, dim3((n + 255) / 256), dim3(256), 0, s, sc->counters,
                          (unsigned)sc->cap_list, sc->slots, sc->nslots, fx, fy, fval);
@@ -632,36 +696,15 @@ __global__ __launch_bounds__(MT) void k_u_round(unsigned *__restrict__ state, in
   if (left) atomicAdd(&counters[round], (unsigned)left);
 }
 
-__global__ void k_u_collect(const unsigned *__restrict__ state, int w, int h, UGrid g,
-                            unsigned long long *__restrict__ keys, unsigned *__restrict__ pos,
-                            unsigned *__restrict__ count, unsigned cap) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-  if (x >= w) return;
-  const unsigned s = state[(size_t)y * w + x];
-  if (s & kAccepted) {
-    const unsigned i = atomicAdd(count, 1u);
-    if (i < cap) {
-      keys[i] = ukey(s & ~kAccepted, x, y, g);
-      pos[i] = (unsigned)(y * w + x);
-    }
-  }
-}
-
-// rank[i] = number of keys greater than keys[i]
-__global__ __launch_bounds__(256) void k_u_rank(const unsigned long long *__restrict__ keys,
-                                                unsigned n, unsigned *__restrict__ rank) {
-  __shared__ unsigned long long tile[256];
-  const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  const unsigned long long own = i < n ? keys[i] : 0ull;
-  unsigned rk = 0;
-  for (unsigned j0 = 0; j0 < n; j0 += 256) {
-    tile[threadIdx.x] = j0 + threadIdx.x < n ? keys[j0 + threadIdx.x] : 0ull;
-    __syncthreads();
-    const unsigned m = min(256u, n - j0);
-    for (unsigned j = 0; j < m; ++j) rk += tile[j] > own;
-    __syncthreads();
-  }
-  if (i < n) rank[i] = rk;
+__global__ __launch_bounds__(256) void k_u_collect(const unsigned *__restrict__ state, int w,
+                                                   int h, UGrid g,
+                                                   unsigned long long *__restrict__ keys,
+                                                   unsigned *__restrict__ pos,
+                                                   unsigned *__restrict__ count, unsigned cap) {
+  collect_block(state, w, h, count, cap, [&](unsigned i, int x, int y, unsigned s) {
+    keys[i] = ukey(s, x, y, g);
+    pos[i] = (unsigned)(y * w + x);
+  });
 }
 
 // out[0] = key, out[1] = pos of the entry whose rank is `target`
@@ -803,11 +846,8 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
                             sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
-    for (int k = first; k < round; ++k) {
-      if (getenv("GKLT_SELECT_TRACE"))
-        fprintf(stderr, "uni round %d caps %d left %u\n", k, caps.enabled, sc->h_counters[k]);
+    for (int k = first; k < round; ++k)
       if (sc->h_counters[k] == 0) done = true;
-    }
     if (!done && round > kMaxRounds) {
       set_error("uniform selection did not converge in %d rounds", kMaxRounds);
       return GKLT_EHIP;
@@ -875,8 +915,8 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
 
   auto collect_and_rank = [&](unsigned *n_acc) -> int {
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned), s));
-    hipLaunchKernelGGL(k_u_collect, pgrid, dim3(256), 0, s, sc->state, w, h, g, sc->list, u->pos,
-                       sc->counters, (unsigned)sc->cap_list);
+    hipLaunchKernelGGL(k_u_collect, collect_grid(w, h), dim3(256), 0, s, sc->state, w, h, g,
+                       sc->list, u->pos, sc->counters, (unsigned)sc->cap_list);
     GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
     *n_acc = sc->h_counters[0];
@@ -884,9 +924,11 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
       set_error("accepted-feature list overflow");
       return GKLT_ECAPACITY;
     }
-    if (*n_acc)
-      hipLaunchKernelGGL(k_u_rank, dim3((*n_acc + 255) / 256), dim3(256), 0, s, sc->list, *n_acc,
-                         u->rank);
+    if (*n_acc) {
+      GKLT_HIP(hipMemsetAsync(u->rank, 0, sizeof(unsigned) * *n_acc, s));
+      hipLaunchKernelGGL(k_rank_partial, dim3((*n_acc + 255) / 256, kRankSlices), dim3(256), 0, s,
+                         sc->list, *n_acc, u->rank);
+    }
     GKLT_HIP(hipGetLastError());
     return 0;
   };

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gslam_amd import klt, synth
 
+VAR = {"uniform": klt.VARIANT_UNIFORM, "plain": klt.VARIANT_PLAIN, "round2": klt.VARIANT_ROUND2}[
+    sys.argv[1] if len(sys.argv) > 1 else "uniform"]
 cfg = dict(synth.CONFIGS["C2"]); H, W, n = cfg["H"], cfg["W"], cfg["n"]
 gp = klt.make_params(window=7, levels=4, min_eigenvalue=100, mindist=10)
 gp.bordery = max(gp.bordery, 24)
@@ -22,7 +24,7 @@ def run(K, t0=0):
     for t in range(t0, t0 + K):
         cur, nxt = ring[t % 3], ring[(t + 1) % 3]
         nxt.build_from_device(ptrs[(t + 1) % 16], W)
-        klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, klt.VARIANT_UNIFORM, fl, grid=(32, 32))
+        klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, VAR, fl, grid=(32, 32))
         klt.track_flist(ctx, cur, nxt, fl)
     ctx.sync()
 
