@@ -186,66 +186,161 @@ __device__ __forceinline__ unsigned long long prio_key(unsigned val, int x, int 
          (unsigned long long)(0xFFFF - x);
 }
 
-// counters[0] = undecided candidates left after this round (summed over tiles)
-__global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
-                                                  int r, unsigned *__restrict__ counters,
-                                                  int round) {
+// LDS layout of a round: key[inH][S] (u64), rmax[inH][MW+1] (u64), acc[inH][S] (u8),
+// racc[inH][MW+1] (u8), with S = inW + 1.  The odd row strides make accesses with lane <-> row
+// conflict-free (row pass) as well as those with lane <-> column (column pass).
+__host__ __device__ inline int mis_stride(int r) { return MW + 2 * r + 1; }
+inline size_t mis_lds_bytes(int r) {
+  const size_t inH = MH + 2 * r, S = mis_stride(r);
+  return 8 * (inH * S + inH * (MW + 1)) + inH * S + inH * (MW + 1);
+}
+
+// m[i] / o[i] = max of k / OR of a over the window [i, i + 2r] of a strided sequence, for G
+// consecutive i.  All G windows share the middle [G-1, 2r]; each adds a suffix of the first G-1
+// and a prefix of the last G-1 elements: 2r + G reads for G outputs instead of G * (2r + 1).
+template <int G>
+__device__ __forceinline__ void window_group(const unsigned long long *k, const unsigned char *a,
+                                             int sk, int sa, int r, unsigned long long (&m)[G],
+                                             unsigned (&o)[G]) {
+  const int L2 = 2 * r;
+  if (L2 >= G - 1) {
+    unsigned long long cm = 0;
+    unsigned co = 0;
+    for (int j = G - 1; j <= L2; ++j) {
+      cm = max(cm, k[j * sk]);
+      co |= a[j * sa];
+    }
+    m[G - 1] = cm;
+    o[G - 1] = co;
+    unsigned long long sm = 0;
+    unsigned so = 0;
+#pragma unroll
+    for (int i = G - 2; i >= 0; --i) {
+      sm = max(sm, k[i * sk]);
+      so |= a[i * sa];
+      m[i] = max(cm, sm);
+      o[i] = co | so;
+    }
+    unsigned long long pm = 0;
+    unsigned po = 0;
+#pragma unroll
+    for (int i = 1; i < G; ++i) {
+      pm = max(pm, k[(L2 + i) * sk]);
+      po |= a[(L2 + i) * sa];
+      m[i] = max(m[i], pm);
+      o[i] |= po;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      unsigned long long mm = 0;
+      unsigned oo = 0;
+      for (int j = 0; j <= L2; ++j) {
+        mm = max(mm, k[(i + j) * sk]);
+        oo |= a[(i + j) * sa];
+      }
+      m[i] = mm;
+      o[i] = oo;
+    }
+  }
+}
+
+// One fixpoint round on the 64x16 tile of this workgroup, shared by the plain and the Uniform
+// selector.  keyf(score, x, y) is the priority key of an undecided candidate; decide(gi, x, y,
+// own, covered, is_max) applies the round's rule to one undecided pixel and returns 1 if it stays
+// undecided.  The haloed tile (keys of undecided pixels, flags of accepted ones) is staged in
+// LDS, followed by a separable (2r+1)-window max of the keys / OR of the flags.
+template <typename KeyF, typename DecideF>
+__device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ state, int w, int h,
+                                               int r, unsigned *__restrict__ counter, KeyF keyf,
+                                               DecideF decide) {
   extern __shared__ __align__(16) unsigned long long lds64[];
-  const int inW = MW + 2 * r, inH = MH + 2 * r;
-  unsigned long long *key = lds64;             // inH x inW : key of undecided, 0 otherwise
-  unsigned long long *rmax = key + inW * inH;  // inH x MW  : row-window max (bit 0 of low word
-                                               //             is not used by keys: y,x < 65535)
-  unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * MW);  // inH x inW accepted
-  unsigned char *racc = acc + inW * inH;                                    // inH x MW
+  const int inW = MW + 2 * r, inH = MH + 2 * r, S = mis_stride(r), SR = MW + 1;
+  unsigned long long *key = lds64;          // inH x S  : key of undecided, 0 otherwise
+  unsigned long long *rmax = key + inH * S; // inH x SR : row-window max
+  unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * SR);  // inH x S accepted
+  unsigned char *racc = acc + inH * S;                                      // inH x SR
   __shared__ int any_undecided;
   const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
   if (threadIdx.x == 0) any_undecided = 0;
   __syncthreads();
+  // staging in batches of kStage unconditional (clamped) loads per thread, so that a batch is in
+  // flight together instead of one load per round trip
   int mine = 0;
-  for (int i = threadIdx.x; i < inW * inH; i += MT) {
-    const int ty = i / inW, tx = i - ty * inW;
-    const int x = x0 - r + tx, y = y0 - r + ty;
-    unsigned s = 0;
-    if (x >= 0 && x < w && y >= 0 && y < h) s = state[(size_t)y * w + x];
-    const bool a = (s & kAccepted) != 0;
-    key[i] = (s != 0 && !a) ? prio_key(s, x, y) : 0ull;
-    acc[i] = a;
-    if (s != 0 && !a && tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
+  constexpr int kStage = 12;
+  const int total = inW * inH;
+  for (int i0 = threadIdx.x; i0 < total; i0 += kStage * MT) {
+    unsigned sv[kStage];
+    int txv[kStage], tyv[kStage];
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int i = min(i0 + u * MT, total - 1);
+      tyv[u] = i / inW;
+      txv[u] = i - tyv[u] * inW;
+      const int x = x0 - r + txv[u], y = y0 - r + tyv[u];
+      const unsigned v = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
+      sv[u] = (x >= 0 && x < w && y >= 0 && y < h) ? v : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      if (i0 + u * MT < total) {
+        const int tx = txv[u], ty = tyv[u];
+        const unsigned s = sv[u];
+        const bool a = (s & kAccepted) != 0;
+        key[ty * S + tx] = (s != 0 && !a) ? keyf(s, x0 - r + tx, y0 - r + ty) : 0ull;
+        acc[ty * S + tx] = a;
+        if (s != 0 && !a && tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
+      }
+    }
   }
   if (mine) any_undecided = 1;
   __syncthreads();
   if (!any_undecided) return;  // nothing to decide in this tile
-  for (int i = threadIdx.x; i < inH * MW; i += MT) {
-    const int ty = i / MW, tx = i % MW;
-    const unsigned long long *k = key + ty * inW + tx;
-    const unsigned char *a = acc + ty * inW + tx;
-    unsigned long long m = 0;
-    unsigned char o = 0;
-    for (int j = 0; j <= 2 * r; ++j) {
-      m = max(m, k[j]);
-      o |= a[j];
+  constexpr int GR = 8, GC = 4;
+  // row pass: lane <-> row, 8 adjacent outputs per task
+  for (int t = threadIdx.x; t < inH * (MW / GR); t += MT) {
+    const int ty = t % inH, gq = t / inH;
+    unsigned long long m[GR];
+    unsigned o[GR];
+    window_group<GR>(key + ty * S + GR * gq, acc + ty * S + GR * gq, 1, 1, r, m, o);
+#pragma unroll
+    for (int i = 0; i < GR; ++i) {
+      rmax[ty * SR + GR * gq + i] = m[i];
+      racc[ty * SR + GR * gq + i] = (unsigned char)o[i];
     }
-    rmax[i] = m;
-    racc[i] = o;
   }
   __syncthreads();
+  // column pass: lane <-> column, 4 outputs (rows) per task
   int left = 0;
-  for (int i = threadIdx.x; i < MH * MW; i += MT) {
-    const int ty = i / MW, tx = i % MW;
-    const unsigned long long own = key[(ty + r) * inW + tx + r];
-    if (own == 0) continue;
-    unsigned long long m = 0;
-    unsigned char o = 0;
-    for (int j = 0; j <= 2 * r; ++j) {
-      m = max(m, rmax[(ty + j) * MW + tx]);
-      o |= racc[(ty + j) * MW + tx];
+  for (int t = threadIdx.x; t < MW * (MH / GC); t += MT) {
+    const int tx = t % MW, gq = t / MW;
+    unsigned long long m[GC];
+    unsigned o[GC];
+    window_group<GC>(rmax + GC * gq * SR + tx, racc + GC * gq * SR + tx, SR, SR, r, m, o);
+#pragma unroll
+    for (int i = 0; i < GC; ++i) {
+      const int ty = GC * gq + i;
+      const unsigned long long own = key[(ty + r) * S + tx + r];
+      if (own == 0) continue;
+      left += decide((size_t)(y0 + ty) * w + x0 + tx, x0 + tx, y0 + ty, own, o[i] != 0, m[i] == own);
     }
-    const size_t gi = (size_t)(y0 + ty) * w + x0 + tx;
-    if (o) state[gi] = 0;                                     // an accepted neighbour covers it
-    else if (m == own) state[gi] = (unsigned)(own >> 32) | kAccepted;
-    else ++left;
   }
-  if (left) atomicAdd(&counters[round], (unsigned)left);
+  if (left) atomicAdd(counter, (unsigned)left);
+}
+
+// counters[round] = undecided candidates left after this round (summed over tiles)
+__global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
+                                                  int r, unsigned *__restrict__ counters,
+                                                  int round) {
+  mis_round_tile(
+      state, w, h, r, counters + round,
+      [](unsigned s, int x, int y) { return prio_key(s, x, y); },
+      [&](size_t gi, int, int, unsigned long long own, bool covered, bool is_max) -> int {
+        if (covered) state[gi] = 0;  // an accepted neighbour covers it
+        else if (is_max) state[gi] = (unsigned)(own >> 32) | kAccepted;
+        else return 1;
+        return 0;
+      });
 }
 
 // Appends the accepted pixels of a 256-column x 32-row block to a list, emit(i, x, y, score)
@@ -507,8 +602,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
 
   // fixpoint rounds (r < 0 happens for mindist 0: every candidate is accepted in one round)
   const int rr = std::max(r, 0);
-  const size_t lds = (size_t)8 * ((MW + 2 * rr) * (MH + 2 * rr) + (MH + 2 * rr) * MW) +
-                     (size_t)(MW + 2 * rr) * (MH + 2 * rr) + (size_t)(MH + 2 * rr) * MW;
+  const size_t lds = mis_lds_bytes(rr);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", P.mindist, lds);
     return GKLT_EINVAL;
@@ -623,77 +717,30 @@ __global__ void k_u_cellmax(const unsigned *__restrict__ state, int w, int h, UG
 __global__ __launch_bounds__(MT) void k_u_round(unsigned *__restrict__ state, int w, int h, int r,
                                                 UGrid g, UCaps caps,
                                                 unsigned *__restrict__ counters, int round) {
-  extern __shared__ __align__(16) unsigned long long lds64[];
-  const int inW = MW + 2 * r, inH = MH + 2 * r;
-  unsigned long long *key = lds64;
-  unsigned long long *rmax = key + inW * inH;
-  unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * MW);
-  unsigned char *racc = acc + inW * inH;
-  __shared__ int any_undecided;
-  const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
-  if (threadIdx.x == 0) any_undecided = 0;
-  __syncthreads();
-  int mine = 0;
-  for (int i = threadIdx.x; i < inW * inH; i += MT) {
-    const int ty = i / inW, tx = i - ty * inW;
-    const int x = x0 - r + tx, y = y0 - r + ty;
-    unsigned s = 0;
-    if (x >= 0 && x < w && y >= 0 && y < h) s = state[(size_t)y * w + x];
-    const bool a = (s & kAccepted) != 0;
-    key[i] = (s != 0 && !a) ? ukey(s, x, y, g) : 0ull;
-    acc[i] = a;
-    if (s != 0 && !a && tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
-  }
-  if (mine) any_undecided = 1;
-  __syncthreads();
-  if (!any_undecided) return;
-  for (int i = threadIdx.x; i < inH * MW; i += MT) {
-    const int ty = i / MW, tx = i % MW;
-    const unsigned long long *k = key + ty * inW + tx;
-    const unsigned char *a = acc + ty * inW + tx;
-    unsigned long long m = 0;
-    unsigned char o = 0;
-    for (int j = 0; j <= 2 * r; ++j) {
-      m = max(m, k[j]);
-      o |= a[j];
-    }
-    rmax[i] = m;
-    racc[i] = o;
-  }
-  __syncthreads();
-  int left = 0;
-  for (int i = threadIdx.x; i < MH * MW; i += MT) {
-    const int ty = i / MW, tx = i % MW;
-    const unsigned long long own = key[(ty + r) * inW + tx + r];
-    if (own == 0) continue;
-    unsigned long long m = 0;
-    unsigned char o = 0;
-    for (int j = 0; j <= 2 * r; ++j) {
-      m = max(m, rmax[(ty + j) * MW + tx]);
-      o |= racc[(ty + j) * MW + tx];
-    }
-    const int x = x0 + tx, y = y0 + ty;
-    const size_t gi = (size_t)y * w + x;
-    const unsigned val = (unsigned)((own >> 16) & 0x7fffffffu);
-    if (o) {
-      state[gi] = 0;
-    } else if (!caps.enabled) {
-      if (m == own) state[gi] = val | kAccepted; else ++left;
-    } else {
-      const int c = ucell(x, y, g);
-      const int rk = 0xFFFF - (int)(own >> 48);
-      const int cap = rk < caps.rankT ? 0x7fffffff : (rk == caps.rankT ? caps.capT : caps.capAfter);
-      if (caps.cellcount[c] >= cap) {
-        state[gi] = 0;                       // the cell is full (:1253-1254)
-      } else if (m == own && caps.cellmax[c] == own) {
-        state[gi] = val | kAccepted;
-        atomicAdd(&caps.cellcount[c], 1);
-      } else {
-        ++left;
-      }
-    }
-  }
-  if (left) atomicAdd(&counters[round], (unsigned)left);
+  mis_round_tile(
+      state, w, h, r, counters + round,
+      [&](unsigned s, int x, int y) { return ukey(s, x, y, g); },
+      [&](size_t gi, int x, int y, unsigned long long own, bool covered, bool is_max) -> int {
+        const unsigned val = (unsigned)((own >> 16) & 0x7fffffffu);
+        if (covered) {
+          state[gi] = 0;
+        } else if (!caps.enabled) {
+          if (is_max) state[gi] = val | kAccepted; else return 1;
+        } else {
+          const int c = ucell(x, y, g);
+          const int rk = 0xFFFF - (int)(own >> 48);
+          const int cap = rk < caps.rankT ? 0x7fffffff : (rk == caps.rankT ? caps.capT : caps.capAfter);
+          if (caps.cellcount[c] >= cap) {
+            state[gi] = 0;                       // the cell is full (:1253-1254)
+          } else if (is_max && caps.cellmax[c] == own) {
+            state[gi] = val | kAccepted;
+            atomicAdd(&caps.cellcount[c], 1);
+          } else {
+            return 1;
+          }
+        }
+        return 0;
+      });
 }
 
 __global__ __launch_bounds__(256) void k_u_collect(const unsigned *__restrict__ state, int w,
@@ -817,8 +864,7 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
 static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
                       UCaps caps, int r, int *round_io) {
   const int w = sc->w, h = sc->h;
-  const size_t lds = (size_t)8 * ((MW + 2 * r) * (MH + 2 * r) + (MH + 2 * r) * MW) +
-                     (size_t)(MW + 2 * r) * (MH + 2 * r) + (size_t)(MH + 2 * r) * MW;
+  const size_t lds = mis_lds_bytes(r);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", r, lds);
     return GKLT_EINVAL;
