@@ -382,6 +382,22 @@ extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level,
   return 0;
 }
 
+// pyramid[3*level].convertTo(ucharImage, CV_8UC1), System.cpp:403: what the keyframe path reads
+extern "C" int gklt_pyramid_download_u8(gklt_ctx *ctx, gklt_pyramid *py, int level, uint8_t *dst,
+                                        int dst_stride) {
+  if (!ctx || !py || !dst || level < 0 || level >= py->nlevels) return GKLT_EINVAL;
+  const Level &L = py->lv[level];
+  if (dst_stride < L.w) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_pyr;
+  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  uint8_t *tmp = reinterpret_cast<uint8_t *>(py->tmp);
+  if (int rc = launch_tex_to_u8(ctx, s, L.tex, L.w * L.h, tmp)) return rc;
+  GKLT_HIP(hipMemcpy2DAsync(dst, dst_stride, tmp, L.w, L.w, L.h, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 extern "C" int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *py, int level, int plane,
                                    const float *src, int src_stride) {
   if (!ctx || !py || !src || level < 0 || level >= py->nlevels || plane < 0 || plane > 2)

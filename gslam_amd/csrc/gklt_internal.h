@@ -133,6 +133,7 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out);
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);
+int launch_tex_to_u8(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, uint8_t *dst);
 int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp, const float *src);
 
 // tracker (gklt_track.hip)

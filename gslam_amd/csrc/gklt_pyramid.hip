@@ -686,6 +686,15 @@ __global__ void k_tex_extract(const Texel *__restrict__ tex, int n, int comp,
   dst[i] = comp == 0 ? t.x : (comp == 1 ? t.y : t.z);
 }
 
+// cv::Mat::convertTo(CV_8UC1) of the image plane (System.cpp:403): saturate_cast<uchar>(cvRound(v)),
+// cvRound = round half to even
+__global__ void k_tex_to_u8(const Texel *__restrict__ tex, int n, uint8_t *__restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int v = __float2int_rn(tex[i].x);
+  dst[i] = (uint8_t)min(max(v, 0), 255);
+}
+
 __global__ void k_tex_insert(Texel *__restrict__ tex, int n, int comp,
                              const float *__restrict__ src) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -891,6 +900,13 @@ int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, in
                        float *dst) {
   ProfScope ps(ctx, s, GKLT_K_MISC);
   hipLaunchKernelGGL(k_tex_extract, dim3((n + 255) / 256), dim3(256), 0, s, tex, n, comp, dst);
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_tex_to_u8(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, uint8_t *dst) {
+  ProfScope ps(ctx, s, GKLT_K_MISC);
+  hipLaunchKernelGGL(k_tex_to_u8, dim3((n + 255) / 256), dim3(256), 0, s, tex, n, dst);
   GKLT_HIP(hipGetLastError());
   return 0;
 }

@@ -261,6 +261,14 @@ class Pyramid:
         _check(lib().gklt_pyramid_download(self.ctx.h, self.h, level, plane, _fp(out), w))
         return out
 
+    def plane_u8(self, level):
+        """pyramid[3*level].convertTo(CV_8UC1) (System.cpp:403)."""
+        w, h = self.level_size(level)
+        out = np.empty((h, w), np.uint8)
+        _check(lib().gklt_pyramid_download_u8(self.ctx.h, self.h, level,
+                                              out.ctypes.data_as(C.POINTER(C.c_uint8)), w))
+        return out
+
     def planes(self):
         return [self.plane(l, c) for l in range(self.nlevels) for c in range(3)]
 

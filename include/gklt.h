@@ -110,6 +110,12 @@ int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *pyr, const uint8_t *img, int
  * This is pyramid[3*level+plane] of the reference's std::vector<cv::Mat>.  Synchronous. */
 int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *pyr, int level, int plane, float *dst,
                           int dst_stride);
+/* The image plane of `level` as 8-bit: pyramid[3*level].convertTo(ucharImage, CV_8UC1)
+ * (System.cpp:403,672: the coarsest level handed to the ORB keyframe path), i.e.
+ * saturate_cast<uchar>(cvRound(v)) with round-half-to-even.  dst_stride in bytes.  A quarter of the
+ * bytes of the float download and no host conversion pass.  Synchronous. */
+int gklt_pyramid_download_u8(gklt_ctx *ctx, gklt_pyramid *pyr, int level, uint8_t *dst,
+                             int dst_stride);
 /* Overwrites one plane from host memory (tests: track on externally produced pyramids). */
 int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *pyr, int level, int plane, const float *src,
                         int src_stride);

@@ -145,3 +145,27 @@ def test_full_size_1080p_properties(klt, ok, gpu_ctx):
     ok.set_threads(1)
     for i, (a, b) in enumerate(zip(got, ref)):
         _assert_bits(a, b, "1080p level %d plane %d" % (i // 3, i % 3))
+
+
+def test_coarsest_level_as_u8(klt, ok, gpu_ctx):
+    """System.cpp:403: pyramid[3*(L-1)].convertTo(ucharImage, CV_8UC1) -- cvRound (half to even) and
+    saturation -- done on the device so that the keyframe path downloads bytes."""
+    H, W = 270, 480
+    img = _frame(H, W)
+    gp = klt.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        pyr.build(img)
+        for level in range(3):
+            f = pyr.plane(level, 0)
+            ref = np.clip(np.rint(f.astype(np.float64)), 0, 255).astype(np.uint8)   # rint = half to even
+            assert (pyr.plane_u8(level) == ref).all()
+        # exact halves and out-of-range values
+        w, h = pyr.level_size(2)
+        crafted = np.zeros((h, w), np.float32)
+        crafted.flat[:8] = [0.5, 1.5, 2.5, -3.0, 254.5, 255.5, 300.0, 127.49]
+        pyr.upload(2, 0, crafted)
+        assert list(pyr.plane_u8(2).flat[:8]) == [0, 2, 2, 0, 254, 255, 255, 127]
+    finally:
+        pyr.close()
