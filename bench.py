@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--lookahead", type=int, default=16,
                     help="frames per gklt_lookahead_submit (0 = gklt_pipeline_step, frame at a time)")
     ap.add_argument("--track-waves", type=int, default=0, help="wavefronts per tracker launch (0 = library default)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--main-only", action="store_true",
                     help="timed + roofline legs only (for rocprofv3 runs: the frame-at-a-time and latency "
@@ -254,7 +256,7 @@ def main():
     H, W, n = cfg["H"], cfg["W"], cfg["n"]
     params_kw = dict(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
     gp = klt.make_params(**params_kw)
-    ctx = klt.Context(local_rank, gp)
+    ctx = klt.Context(0 if a.share_gpu else local_rank, gp)
     ctx.set_track_waves(a.track_waves)
 
     seed = rank_seed(rank)
