@@ -279,8 +279,7 @@ struct BuildTaps {
   gklt::Taps smooth0, pyr, gradg, gradd;
 };
 
-// kernels for this call: the reference recomputes them on every call
-int build_taps(const gklt_params &P, int nlevels, BuildTaps *t) {
+int build_taps_uncached(const gklt_params &P, int nlevels, BuildTaps *t) {
   float g[GKLT_MAX_KERNEL_WIDTH], d[GKLT_MAX_KERNEL_WIDTH];
   int gw, dw;
   if (int rc = gklt_compute_kernels(gklt_compute_smooth_sigma(&P), g, &gw, d, &dw)) return rc;
@@ -293,6 +292,35 @@ int build_taps(const gklt_params &P, int nlevels, BuildTaps *t) {
   if (int rc = gklt_compute_kernels(P.grad_sigma, g, &gw, d, &dw)) return rc;  // pyramid.cpp:69-71
   gklt::half_taps(g, gw, +1, &t->gradg);
   gklt::half_taps(d, dw, -1, &t->gradd);
+  return 0;
+}
+
+// Kernels of a build.  The reference recomputes them on every call; computeKernels
+// costs ~6 us of host time per sigma (71 exp() evaluations and two normalisations), three times
+// what a kernel launch costs, so the taps of the last (sigma0, sigma_pyr, sigma_grad, levels)
+// are kept per thread.
+int build_taps(const gklt_params &P, int nlevels, BuildTaps *t) {
+  struct Cache {
+    bool valid = false;
+    float s0 = 0, sp = 0, sg = 0;
+    bool multi = false;
+    BuildTaps taps;
+  };
+  static thread_local Cache cache;
+  const float s0 = gklt_compute_smooth_sigma(&P), sp = P.subsampling * P.pyramid_sigma_fact;
+  if (cache.valid && cache.s0 == s0 && cache.sp == sp && cache.sg == P.grad_sigma &&
+      cache.multi == (nlevels > 1)) {
+    *t = cache.taps;
+    return 0;
+  }
+  cache.valid = false;
+  if (int rc = build_taps_uncached(P, nlevels, t)) return rc;
+  cache.taps = *t;
+  cache.s0 = s0;
+  cache.sp = sp;
+  cache.sg = P.grad_sigma;
+  cache.multi = nlevels > 1;
+  cache.valid = true;
   return 0;
 }
 

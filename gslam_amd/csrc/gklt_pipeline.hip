@@ -6,8 +6,8 @@
 // launch costs ~2.4 us of host time, a cross-stream event record+wait pair ~7 us, a forked HIP
 // graph ~50 us per replay, a 48 KB D2H copy ~12 us on its stream): no graphs, no fork/join.
 // Two streams alternate by frame parity.  Step t enqueues
-//     stream (t+1)%2 :  B(t+1)   build of the next frame's pyramid (5 launches)
-//     stream  t   %2 :  T(t)     tracker previous -> current       (1 launch)
+//     stream  t   %2 :  T(t)     tracker previous -> current       (1 launch, enqueued first)
+//     stream (t+1)%2 :  B(t+1)   build of the next frame's pyramid (one launch per level)
 // so every stream runs ... B(k), T(k), B(k+2), T(k+2) ... in order.  T(t) follows B(t) on its own
 // stream and waits (the only event pair of the step) for T(t-1) on the other stream, which it needs
 // anyway for the feature list and which also covers B(t-1).  B(t+2) overwrites the ring slot of
@@ -93,6 +93,19 @@ extern "C" int gklt_pipeline_sync(gklt_pipeline *p) {
   return gklt_sync(p->ctx);
 }
 
+// Waits until the list of the last step is complete (on the device and, if the step had a
+// host_out, in host memory); the build of the next frame keeps running.
+extern "C" int gklt_pipeline_wait_tracked(gklt_pipeline *p) {
+  if (!p) return GKLT_EINVAL;
+  if (int rc = dev(p)) return rc;
+  if (!p->started) return 0;
+  // the last tracker ran on the stream of frame t-1 (t was advanced by the step) or, for the
+  // final track-only step, of frame t: the newer of the two events covers both
+  for (int i = 0; i < 2; ++i)
+    if (p->has_trk[i]) GKLT_HIP(hipEventSynchronize(p->e_trk[i]));
+  return 0;
+}
+
 extern "C" int gklt_pipeline_destroy(gklt_pipeline *p) {
   if (!p) return 0;
   (void)hipSetDevice(p->ctx->device);
@@ -141,10 +154,9 @@ extern "C" int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int
     set_error("context levels/subsampling changed after the pipeline was created");
     return GKLT_EINVAL;
   }
-  // B(t+1): the preload of System.cpp:508-511
-  if (img_next)
-    if (int rc = enqueue_frame_build(p, t + 1, img_next, stride, on_device)) return rc;
-  // T(t): KLTTrackFeatures(pyramid t-1, pyramid t), System.cpp:515-518
+  // T(t): KLTTrackFeatures(pyramid t-1, pyramid t), System.cpp:515-518.  Enqueued BEFORE the
+  // build of the next frame: the two are independent, and the 4 launches of the build cost
+  // ~16 us of host time that would otherwise delay the frame's result.
   const int si = (int)(t & 1), so = si ^ 1;
   hipStream_t s = p->st[si];
   if (p->has_trk[so]) GKLT_HIP(hipStreamWaitEvent(s, p->e_trk[so], 0));
@@ -163,6 +175,9 @@ extern "C" int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int
                             hipMemcpyDeviceToHost, s));
   GKLT_HIP(hipEventRecord(p->e_trk[si], s));
   p->has_trk[si] = true;
+  // B(t+1): the preload of System.cpp:508-511, on the other stream
+  if (img_next)
+    if (int rc = enqueue_frame_build(p, t + 1, img_next, stride, on_device)) return rc;
   if (img_next) p->t = t + 1;  // PyramidBuffer::next(), System.h:47-55
   return 0;
 }

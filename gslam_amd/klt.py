@@ -378,6 +378,10 @@ class Pipeline:
     def sync(self):
         _check(lib().gklt_pipeline_sync(self.h))
 
+    def wait_tracked(self):
+        """waits for the list of the last step only (the next frame's build keeps running)"""
+        _check(lib().gklt_pipeline_wait_tracked(self.h))
+
     def pyramid(self, which):
         """which = 0 previous, 1 current (after sync)."""
         py = Pyramid.__new__(Pyramid)

@@ -224,6 +224,10 @@ int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int stride, in
 int gklt_pipeline_upload_features(gklt_pipeline *p, int n, const float *x, const float *y,
                                   const int *val);
 int gklt_pipeline_sync(gklt_pipeline *p);
+/* Waits only for the list of the last step (device list and host_out complete); the pyramid build
+ * of the next frame, which the step enqueued after the tracker, keeps running in the background.
+ * This is the point at which System::Track can go on (it needs the list, not the next pyramid). */
+int gklt_pipeline_wait_tracked(gklt_pipeline *p);
 /* The list the pipeline tracks, and its pyramids (which = 0 previous, 1 current) for downloads;
  * call gklt_pipeline_sync() first. */
 gklt_flist *gklt_pipeline_flist(gklt_pipeline *p);

@@ -324,3 +324,36 @@ def test_build_and_track_from_two_host_threads(klt, ok, gpu_ctx):
         rx, ry, rv = ok.track_features(op, prev, cur, rx, ry, rv)[:3]
         _assert_same(got[t - 1], (rx, ry, rv))
         prev = cur
+
+
+def test_pipeline_wait_tracked_delivers_the_list(klt, ok, gpu_ctx):
+    """gklt_pipeline_wait_tracked: after it returns the frame's list is complete in pinned host
+    memory although the next frame's build may still be running."""
+    H, W, nfr, n = 180, 320, 6, 256
+    f = _stream(H, W, nfr, seed=41)
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    pipe = klt.Pipeline(gpu_ctx, W, H, n)
+    out, out_ptr = gpu_ctx.pinned_array((3, n), np.float32)
+    got = []
+    try:
+        pipe.upload_features(x, y, val)
+        pipe.start(f[0], f[1])
+        for t in range(1, nfr):
+            pipe.step(f[t + 1] if t + 1 < nfr else None, out_ptr)
+            pipe.wait_tracked()
+            got.append((out[0].copy(), out[1].copy(), out[2].view(np.int32).copy()))
+        pipe.sync()
+    finally:
+        pipe.close()
+        gpu_ctx.pinned_free(out_ptr)
+    rx, ry, rv = x, y, val
+    prev = ok.compute_pyramid(op, f[0])
+    for t in range(1, nfr):
+        cur = ok.compute_pyramid(op, f[t])
+        rx, ry, rv = ok.track_features(op, prev, cur, rx, ry, rv)[:3]
+        _assert_same(got[t - 1], (rx, ry, rv))
+        prev = cur
