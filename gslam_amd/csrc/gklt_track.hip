@@ -66,9 +66,20 @@ __device__ __forceinline__ Bilin bilinear_weight(float x, float y) {
   b.xt = (int)x;
   b.yt = (int)y;
   const float ax = x - b.xt, ay = y - b.yt;
-  b.w0 = (float)((1.0 - ax) * (1.0 - ay));
-  b.w1 = (float)((ax) * (1.0 - ay));
-  b.w2 = (float)((1.0 - ax) * ay);
+  if (x >= 1.0f && y >= 1.0f) {
+    // Same bits without fp64: for x >= 1 the fraction ax is a multiple of ulp(x) >= 2^-23, so
+    // 1 - ax is exactly representable in fp32, and the double product of two fp32 numbers is
+    // exact, i.e. rounding it to fp32 is the correctly rounded fp32 product.  Every sampled
+    // position satisfies x - hw >= 0 with hw >= 1 (window_oob), so this is the path taken.
+    const float bx = 1.0f - ax, by = 1.0f - ay;
+    b.w0 = bx * by;
+    b.w1 = ax * by;
+    b.w2 = bx * ay;
+  } else {
+    b.w0 = (float)((1.0 - ax) * (1.0 - ay));
+    b.w1 = (float)((ax) * (1.0 - ay));
+    b.w2 = (float)((1.0 - ax) * ay);
+  }
   b.w3 = ax * ay;
   // Integer position: the reference copies rows instead of interpolating (LK.hpp:80-85).  With
   // the other three weights forced to zero the interpolation formula returns the same sample
