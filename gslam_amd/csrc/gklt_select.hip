@@ -252,7 +252,8 @@ __device__ __forceinline__ void window_group(const unsigned long long *k, const 
 // LDS, followed by a separable (2r+1)-window max of the keys / OR of the flags.
 template <typename KeyF, typename DecideF>
 __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ state, int w, int h,
-                                               int r, unsigned *__restrict__ counter, KeyF keyf,
+                                               int r, unsigned *__restrict__ counter,
+                                               unsigned *__restrict__ tile_left, KeyF keyf,
                                                DecideF decide) {
   extern __shared__ __align__(16) unsigned long long lds64[];
   const int inW = MW + 2 * r, inH = MH + 2 * r, S = mis_stride(r), SR = MW + 1;
@@ -261,8 +262,13 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
   unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * SR);  // inH x S accepted
   unsigned char *racc = acc + inH * S;                                      // inH x SR
   __shared__ int any_undecided;
+  __shared__ unsigned blk_left;
   const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
-  if (threadIdx.x == 0) any_undecided = 0;
+  // tile_left = undecided core pixels after the tile's last round (all ones before the first):
+  // a tile that has none left never gets any again and is skipped without staging
+  unsigned *const my_left = tile_left + blockIdx.y * gridDim.x + blockIdx.x;
+  if (*my_left == 0) return;
+  if (threadIdx.x == 0) { any_undecided = 0; blk_left = 0; }
   __syncthreads();
   // staging in batches of kStage unconditional (clamped) loads per thread, so that a batch is in
   // flight together instead of one load per round trip
@@ -295,7 +301,10 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
   }
   if (mine) any_undecided = 1;
   __syncthreads();
-  if (!any_undecided) return;  // nothing to decide in this tile
+  if (!any_undecided) {  // nothing to decide in this tile
+    if (threadIdx.x == 0) *my_left = 0;
+    return;
+  }
   constexpr int GR = 8, GC = 4;
   // row pass: lane <-> row, 8 adjacent outputs per task
   for (int t = threadIdx.x; t < inH * (MW / GR); t += MT) {
@@ -325,15 +334,20 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
       left += decide((size_t)(y0 + ty) * w + x0 + tx, x0 + tx, y0 + ty, own, o[i] != 0, m[i] == own);
     }
   }
-  if (left) atomicAdd(counter, (unsigned)left);
+  if (left) atomicAdd(&blk_left, (unsigned)left);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    *my_left = blk_left;
+    if (blk_left) atomicAdd(counter, blk_left);
+  }
 }
 
 // counters[round] = undecided candidates left after this round (summed over tiles)
 __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
                                                   int r, unsigned *__restrict__ counters,
-                                                  int round) {
+                                                  unsigned *__restrict__ tile_left, int round) {
   mis_round_tile(
-      state, w, h, r, counters + round,
+      state, w, h, r, counters + round, tile_left,
       [](unsigned s, int x, int y) { return prio_key(s, x, y); },
       [&](size_t gi, int, int, unsigned long long own, bool covered, bool is_max) -> int {
         if (covered) state[gi] = 0;  // an accepted neighbour covers it
@@ -497,6 +511,8 @@ struct SelScratch {
   unsigned char *blocked = nullptr;
   unsigned long long *list = nullptr;
   unsigned *rank = nullptr;      // rank of list[i] among the accepted keys
+  unsigned *tile_left = nullptr; // per 64x16 tile: undecided pixels after its last round
+  size_t tile_bytes = 0;
   unsigned *counters = nullptr;  // [0] accepted count, [1..] per-round undecided
   int *slots = nullptr, *nslots = nullptr;
   unsigned *h_counters = nullptr;  // pinned
@@ -514,6 +530,7 @@ void sel_free(SelScratch *s) {
   (void)hipFree(s->blocked);
   (void)hipFree(s->list);
   (void)hipFree(s->rank);
+  (void)hipFree(s->tile_left);
   (void)hipFree(s->counters);
   (void)hipFree(s->slots);
   (void)hipFree(s->nslots);
@@ -542,6 +559,8 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
     GKLT_HIP(hipMalloc(&s->blocked, (size_t)w * h));
     GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * (size_t)s->cap_list));
     GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * (size_t)s->cap_list));
+    s->tile_bytes = sizeof(unsigned) * (size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH);
+    GKLT_HIP(hipMalloc(&s->tile_left, s->tile_bytes));
     GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
     GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
     GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
@@ -611,6 +630,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
     GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mis_round),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH);
+  GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));
   int round = 1;
   bool done = false;
   while (!done) {
@@ -619,7 +639,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
       ProfScope ps(ctx, s, GKLT_K_SELECT);
       for (int b = 0; b < kRoundBatch && round <= kMaxRounds; ++b, ++round)
         hipLaunchKernelGGL(k_mis_round, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
-                           round);
+                           sc->tile_left, round);
     }
     GKLT_HIP(hipGetLastError());
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
@@ -716,9 +736,10 @@ __global__ void k_u_cellmax(const unsigned *__restrict__ state, int w, int h, UG
 
 __global__ __launch_bounds__(MT) void k_u_round(unsigned *__restrict__ state, int w, int h, int r,
                                                 UGrid g, UCaps caps,
-                                                unsigned *__restrict__ counters, int round) {
+                                                unsigned *__restrict__ counters,
+                                                unsigned *__restrict__ tile_left, int round) {
   mis_round_tile(
-      state, w, h, r, counters + round,
+      state, w, h, r, counters + round, tile_left,
       [&](unsigned s, int x, int y) { return ukey(s, x, y, g); },
       [&](size_t gi, int x, int y, unsigned long long own, bool covered, bool is_max) -> int {
         const unsigned val = (unsigned)((own >> 16) & 0x7fffffffu);
@@ -873,6 +894,7 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_u_round),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH), pgrid((w + 255) / 256, h);
+  GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));  // a phase starts: all tiles live
   int round = *round_io;
   bool done = false;
   while (!done) {
@@ -885,7 +907,7 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
           hipLaunchKernelGGL(k_u_cellmax, pgrid, dim3(256), 0, s, sc->state, w, h, g, u->cellmax);
         }
         hipLaunchKernelGGL(k_u_round, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps,
-                           sc->counters, round);
+                           sc->counters, sc->tile_left, round);
       }
     }
     GKLT_HIP(hipGetLastError());
