@@ -34,98 +34,120 @@ constexpr unsigned kAccepted = 0x80000000u;
 // rows x 3 quantities (then columns x 3), so the kernels are built around keeping those chains
 // fed: the loads of the next tile are in flight while the chains of the current one run.
 //
-// Rows: a block of 4 waves owns 64 rows.  Per 64-column tile every wave loads 16 rows
-// row-contiguously (16 loads in flight per lane, issued one tile ahead), the products are
-// transposed through LDS (stride 65: conflict-free both ways), wave q < 3 extends the running
-// prefixes of quantity q (lane = row), and all waves write the prefixes back row-contiguously.
+// Rows: a block of 256 threads owns kIR = 16 rows (68 blocks at 1080p instead of 17 with 64 rows).
+// Per 256-column tile every thread loads one column of the 16 rows (16 loads in flight, issued
+// one tile ahead), the products go to LDS (row stride 257: conflict-free both ways), 48 lanes of
+// wave 0 -- one per (quantity, row) -- extend their running prefixes over the 256 columns, and all
+// threads write the prefixes back row-contiguously.
+constexpr int kIR = 16, kIC = 256;
 __global__ __launch_bounds__(256) void k_integral_rows(const Texel *__restrict__ tex, int w, int h,
                                                        float *__restrict__ sxx,
                                                        float *__restrict__ syy,
                                                        float *__restrict__ sxy) {
-  __shared__ float t[3][64][65];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int y0 = blockIdx.x * 64, w1 = w + 1, r0 = 16 * wave;
-  float run = 0.f;  // waves 0..2: running prefix of quantity `wave`, row y0 + lane
-  float gx[16], gy[16];
+  __shared__ float t[3][kIR][kIC + 1];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int y0 = blockIdx.x * kIR, w1 = w + 1;
+  float run = 0.f;  // wave 0, lane < 48: running prefix of quantity lane / 16, row y0 + lane % 16
+  float gx[kIR], gy[kIR];
   auto load = [&](int x0) {
-    const int col = min(x0 + lane, w - 1);
+    const int col = min(x0 + tid, w - 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {  // clamped, unconditional: all 16 loads are in flight together
-      const Texel v = tex[(size_t)min(y0 + r0 + r, h - 1) * w + col];
+    for (int r = 0; r < kIR; ++r) {  // clamped, unconditional: all 16 loads are in flight together
+      const Texel v = tex[(size_t)min(y0 + r, h - 1) * w + col];
       gx[r] = v.y;
       gy[r] = v.z;
     }
   };
   load(0);
-  for (int x0 = 0; x0 < w; x0 += 64) {
-    const int x = x0 + lane;
+  for (int x0 = 0; x0 < w; x0 += kIC) {
+    const int x = x0 + tid;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool in = x < w && y0 + r0 + r < h;
+    for (int r = 0; r < kIR; ++r) {
+      const bool in = x < w && y0 + r < h;
       const float a = in ? gx[r] : 0.f, b = in ? gy[r] : 0.f;
-      t[0][r0 + r][lane] = a * a;  // cv::multiply, System.cpp:386-388
-      t[1][r0 + r][lane] = b * b;
-      t[2][r0 + r][lane] = a * b;
+      t[0][r][tid] = a * a;  // cv::multiply, System.cpp:386-388
+      t[1][r][tid] = b * b;
+      t[2][r][tid] = a * b;
     }
     __syncthreads();
-    if (x0 + 64 < w) load(x0 + 64);
-    if (wave < 3) {
-      float(*tq)[65] = t[wave];
-      const int nc = min(64, w - x0);
-#pragma unroll 8
+    if (x0 + kIC < w) load(x0 + kIC);
+    if (wave == 0 && lane < 3 * kIR) {
+      float *p = t[lane / kIR][lane % kIR];
+      const int nc = min(kIC, w - x0);
+#pragma unroll 16
       for (int c = 0; c < nc; ++c) {
-        run = run + tq[lane][c];
-        tq[lane][c] = run;
+        run = run + p[c];
+        p[c] = run;
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (x < w && y0 + r0 + r < h) {
-        const size_t o = (size_t)(y0 + r0 + r + 1) * w1 + x + 1;
-        sxx[o] = t[0][r0 + r][lane];
-        syy[o] = t[1][r0 + r][lane];
-        sxy[o] = t[2][r0 + r][lane];
+    for (int r = 0; r < kIR; ++r) {
+      if (x < w && y0 + r < h) {
+        const size_t o = (size_t)(y0 + r + 1) * w1 + x + 1;
+        sxx[o] = t[0][r][tid];
+        syy[o] = t[1][r][tid];
+        sxy[o] = t[2][r][tid];
       }
     }
     __syncthreads();
   }
 }
 
-// sum(y+1, x+1) = sum(y, x+1) + prefix_y(x), in place; row 0 and column 0 are zero.  One thread
-// per column and quantity; rows are taken in groups of 32 with the next group's loads issued
-// before the current group's chain of adds.
-__global__ __launch_bounds__(64) void k_integral_cols(float *__restrict__ sxx,
-                                                      float *__restrict__ syy,
-                                                      float *__restrict__ sxy, int w, int h) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;  // 0..w (column of the (h+1)x(w+1) image)
-  const int w1 = w + 1;
-  if (x > w) return;
+// sum(y+1, x+1) = sum(y, x+1) + prefix_y(x), in place; row 0 and column 0 are zero.  A column is
+// one chain of h adds; a wavefront on its own cannot keep enough loads in flight to feed it (1080
+// loads at <= 63 outstanding and ~2 us each), so the loads are cooperative: a block of 4 waves owns
+// 64 columns of one quantity, every wave loads 16 rows of the next 64-row tiles (two tiles ahead,
+// in registers), the tile goes through LDS, wave 0 -- lane = column -- extends the 64 chains, and
+// all waves write the tile back.
+constexpr int kCT = 64;  // rows per tile
+__global__ __launch_bounds__(256) void k_integral_cols(float *__restrict__ sxx,
+                                                       float *__restrict__ syy,
+                                                       float *__restrict__ sxy, int w, int h) {
+  __shared__ float t[kCT][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int x = blockIdx.x * 64 + lane;  // column of the (h+1) x (w+1) image
+  const int w1 = w + 1, xc = min(x, w);
   float *s = blockIdx.y == 0 ? sxx : (blockIdx.y == 1 ? syy : sxy);
-  s[x] = 0.f;
-  if (x == 0) {
-    for (int y = 1; y <= h; ++y) s[(size_t)y * w1] = 0.f;
-    return;
-  }
-  constexpr int G = 32;
-  float cur[G], nxt[G];
+  if (wave == 0 && x <= w) s[x] = 0.f;  // row 0
+  const int ntiles = (h + kCT - 1) / kCT;
+  float acc = 0.f;  // wave 0: running column sum
+  auto load = [&](float (&v)[16], int k) {
+    const int kc = min(k, ntiles - 1);
 #pragma unroll
-  for (int i = 0; i < G; ++i) cur[i] = s[(size_t)min(1 + i, h) * w1 + x];
-  float acc = 0.f;
-  for (int yb = 1; yb <= h; yb += G) {
-    if (yb + G <= h) {
-#pragma unroll
-      for (int i = 0; i < G; ++i) nxt[i] = s[(size_t)min(yb + G + i, h) * w1 + x];
+    for (int i = 0; i < 16; ++i) {  // clamped, unconditional: 16 loads in flight per register set
+      const int y = min(1 + kc * kCT + 16 * wave + i, h);
+      v[i] = s[(size_t)y * w1 + xc];
     }
+  };
+  auto process = [&](float (&v)[16], int k) {
 #pragma unroll
-    for (int i = 0; i < G; ++i) {
-      if (yb + i <= h) {
-        acc = acc + cur[i];
-        s[(size_t)(yb + i) * w1 + x] = acc;
+    for (int i = 0; i < 16; ++i) t[16 * wave + i][lane] = x == 0 ? 0.f : v[i];  // column 0 is zero
+    __syncthreads();
+    if (k + 2 < ntiles) load(v, k + 2);
+    if (wave == 0) {
+      const int nr = min(kCT, h - k * kCT);
+#pragma unroll 16
+      for (int r = 0; r < nr; ++r) {
+        acc = acc + t[r][lane];
+        t[r][lane] = acc;
       }
     }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < G; ++i) cur[i] = nxt[i];
+    for (int i = 0; i < 16; ++i) {
+      const int y = 1 + k * kCT + 16 * wave + i;
+      if (y <= h && x <= w) s[(size_t)y * w1 + x] = t[16 * wave + i][lane];
+    }
+    __syncthreads();
+  };
+  float a[16], b[16];
+  load(a, 0);
+  load(b, 1);
+  for (int k = 0; k < ntiles; k += 2) {
+    process(a, k);
+    if (k + 1 < ntiles) process(b, k + 1);
   }
 }
 
@@ -575,9 +597,9 @@ int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyram
   const int w = py->lv[0].w, h = py->lv[0].h;
   {
     ProfScope ps(ctx, s, GKLT_K_INTEGRAL);
-    hipLaunchKernelGGL(k_integral_rows, dim3((h + 63) / 64), dim3(256), 0, s, py->lv[0].tex, w, h,
+    hipLaunchKernelGGL(k_integral_rows, dim3((h + kIR - 1) / kIR), dim3(256), 0, s, py->lv[0].tex, w, h,
                        sc->sum[0], sc->sum[1], sc->sum[2]);
-    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(64), 0, s, sc->sum[0],
+    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(256), 0, s, sc->sum[0],
                        sc->sum[1], sc->sum[2], w, h);
   }
   GKLT_HIP(hipGetLastError());
