@@ -31,6 +31,7 @@ struct TrackArgs {
   TrackLevel lv[GKLT_MAX_LEVELS];
   int nlevels;
   float ss;
+  float inv_ss;  // 1 / ss when ss is a power of two (exact), else 0
   int ww, wh;
   float step_factor, min_det, min_disp, max_residue;
   int max_iter;
@@ -496,7 +497,13 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
     continue;
   }
   float xloc = px, yloc = py;
-  for (int r = 0; r < a.nlevels; ++r) { xloc /= a.ss; yloc /= a.ss; }  // LK.hpp:837-839
+  // LK.hpp:837-839.  Dividing by a power of two is the same as multiplying by its (exact)
+  // reciprocal; a correctly rounded fp32 division is ~12 instructions, and there are 2 * levels.
+  if (a.inv_ss != 0.f) {
+    for (int r = 0; r < a.nlevels; ++r) { xloc *= a.inv_ss; yloc *= a.inv_ss; }
+  } else {
+    for (int r = 0; r < a.nlevels; ++r) { xloc /= a.ss; yloc /= a.ss; }
+  }
   float xo = xloc, yo = yloc;
   int v = GKLT_TRACKED;
 
@@ -712,6 +719,7 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
   TrackArgs a{};
   a.nlevels = P.nPyramidLevels;
   a.ss = (float)P.subsampling;  // LK.hpp:978
+  a.inv_ss = (P.subsampling & (P.subsampling - 1)) == 0 ? 1.0f / (float)P.subsampling : 0.f;
   a.ww = P.window_width;
   a.wh = P.window_height;
   a.step_factor = P.step_factor;
