@@ -169,3 +169,36 @@ def test_lookahead_argument_errors(klt, gpu_ctx):
         la.flush()
     finally:
         la.close()
+
+
+@pytest.mark.parametrize("waves", [1, 7, 64])
+def test_lookahead_wavefronts_take_several_features(klt, ok, gpu_ctx, waves):
+    """A multi-frame launch is capped at 3072 wavefronts; each takes features w, w + waves, ...
+    Forced here to a few wavefronts so that every one follows several features through the batch."""
+    H, W, n = 135, 240, 150
+    f = _stream(H, W, 5, seed=13)
+    gp = klt.make_params(window=7, levels=2)
+    op = ok.make_params(window=7, levels=2)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    x[3] = 2.0                      # out of bounds from the start
+    val = np.zeros(n, np.int32)
+    val[11] = -4                    # lost before the batch
+    ref = _oracle_lists(ok, op, f, x, y, val)
+    gpu_ctx.set_track_waves(waves)
+    la = klt.Lookahead(gpu_ctx, W, H, n, 4)
+    outs = [gpu_ctx.pinned_array((3, n), np.float32) for _ in range(4)]
+    try:
+        la.upload_features(x, y, val)
+        la.start(f[0])
+        la.submit(f[1:5], [o[1] for o in outs])
+        la.flush()
+        for k in range(4):
+            _same(outs[k][0], ref[k], "frame %d" % (k + 1))
+        tracked_total, _ = la.flist.stats()
+        assert tracked_total == sum(int((r[2] == 0).sum()) for r in ref)
+    finally:
+        gpu_ctx.set_track_waves(0)
+        la.close()
+        for _, p in outs:
+            gpu_ctx.pinned_free(p)
