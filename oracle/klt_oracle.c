@@ -169,6 +169,31 @@ static inline float corr1d(const float *s, int stride, const float *k, int r, in
   return acc;
 }
 
+/* One filtered row: out[x] = correlation of the taps with s_j[x], j = -r..r, where sp[j] / sm[j]
+ * point at the samples at offset +j / -j.  The loops run tap-outer, pixel-inner, so that the
+ * compiler can vectorise over x; every pixel still sees k0*s0, then + k1*(s1 +- s-1), ... in
+ * this order, i.e. the same rounded operations as the tap-inner form. */
+static void corr_row(float *restrict out, int n, const float *const *sp, const float *const *sm,
+                     const float *restrict s0, const float *K, int r, int sym) {
+  int x, j;
+  if (sym > 0) {
+    const float k0 = K[r];
+    for (x = 0; x < n; x++) out[x] = k0 * s0[x];
+    for (j = 1; j <= r; j++) {
+      const float kj = K[r + j];
+      const float *restrict a = sp[j], *restrict b = sm[j];
+      for (x = 0; x < n; x++) out[x] = out[x] + kj * (a[x] + b[x]);
+    }
+  } else {
+    for (x = 0; x < n; x++) out[x] = 0.0f;
+    for (j = 1; j <= r; j++) {
+      const float kj = K[r + j];
+      const float *restrict a = sp[j], *restrict b = sm[j];
+      for (x = 0; x < n; x++) out[x] = out[x] + kj * (a[x] - b[x]);
+    }
+  }
+}
+
 void ok_sep_filter(const float *src, int W, int H, const float *rowK, int rw, int rsym,
                    const float *colK, int cw, int csym, float *dst) {
   const int rr = rw / 2, cr = cw / 2;
@@ -178,27 +203,22 @@ void ok_sep_filter(const float *src, int W, int H, const float *rowK, int rw, in
   for (y = 0; y < H; y++) {
     float *ext = (float *)malloc((size_t)(W + 2 * rr) * sizeof(float));
     const float *srow = src + (size_t)y * W;
-    int x;
+    const float *sp[35 + 1], *sm[35 + 1];
+    int x, j;
     for (x = -rr; x < W + rr; x++) ext[x + rr] = srow[reflect101(x, W)];
-    for (x = 0; x < W; x++) tmp[(size_t)y * W + x] = corr1d(ext + x + rr, 1, rowK, rr, rsym);
+    for (j = 1; j <= rr; j++) { sp[j] = ext + rr + j; sm[j] = ext + rr - j; }
+    corr_row(tmp + (size_t)y * W, W, sp, sm, ext + rr, rowK, rr, rsym);
     free(ext);
   }
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (y = 0; y < H; y++) {
-    int x, j;
-    const float *rows[2 * 35 + 1];
-    for (j = -cr; j <= cr; j++) rows[j + cr] = tmp + (size_t)reflect101(y + j, H) * W;
-    for (x = 0; x < W; x++) {
-      float acc;
-      if (csym > 0) {
-        acc = colK[cr] * rows[cr][x];
-        for (j = 1; j <= cr; j++) acc = acc + colK[cr + j] * (rows[cr + j][x] + rows[cr - j][x]);
-      } else {
-        acc = 0.0f;
-        for (j = 1; j <= cr; j++) acc = acc + colK[cr + j] * (rows[cr + j][x] - rows[cr - j][x]);
-      }
-      dst[(size_t)y * W + x] = acc;
+    const float *sp[35 + 1], *sm[35 + 1];
+    int j;
+    for (j = 1; j <= cr; j++) {
+      sp[j] = tmp + (size_t)reflect101(y + j, H) * W;
+      sm[j] = tmp + (size_t)reflect101(y - j, H) * W;
     }
+    corr_row(dst + (size_t)y * W, W, sp, sm, tmp + (size_t)y * W, colK, cr, csym);
   }
   free(tmp);
 }
