@@ -401,7 +401,7 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_cpu:
         threads = min(16, len(os.sched_getaffinity(0)))
-        ncpu = a.cpu_frames or (160 if a.config == "C2" else 24)
+        ncpu = a.cpu_frames or {"C2": 160, "Cship": 160, "C3": 48}.get(a.config, 24)
         v, cdt = cpu_baseline(params_kw, frames, seeds, ncpu, threads)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads,
                                "kind": "port",
