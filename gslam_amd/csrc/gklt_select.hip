@@ -543,7 +543,7 @@ struct SelScratch {
 struct UniScratch;
 void uni_free(UniScratch *u);
 constexpr int kMaxRounds = 4096;
-constexpr int kRoundBatch = 8;  // rounds per host sync: a converged round costs ~3 us, a sync ~25 us
+constexpr int kRoundBatch = 24;  // rounds per host sync: a converged round costs ~3 us, a sync ~25 us
 
 void sel_free(SelScratch *s) {
   if (!s) return;
