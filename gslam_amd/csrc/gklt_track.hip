@@ -480,8 +480,15 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
 
   // The grid is capped (launch_track_frames) so that a launch never takes every wave slot of
   // the chip away from the pyramid build it overlaps with; a wavefront then takes features
-  // blockIdx.x, blockIdx.x + gridDim.x, ...
-  for (int f = blockIdx.x; f < a.n; f += gridDim.x) {
+  // blockIdx.x, blockIdx.x + gridDim.x, ... of a permuted list: workgroups go round-robin over
+  // the 8 XCDs (each with its own L2), so slot q is mapped to feature (q % 8) * ceil(n/8) + q / 8
+  // and every XCD works on one contiguous eighth of the list.  Lists are spatially ordered in
+  // practice (selection order, lattice seeds): neighbouring features, whose windows overlap at
+  // the coarse levels, then share an L2.
+  const int per_xcd = (a.n + 7) >> 3;
+  for (int q = blockIdx.x; q < 8 * per_xcd; q += gridDim.x) {
+  const int f = (q & 7) * per_xcd + (q >> 3);
+  if (f >= a.n) continue;
   const int val0 = fval[f];
   float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
   int vcur = val0;
