@@ -730,7 +730,7 @@ extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   return 0;
 }
 
-// wavefronts of a wave-per-feature tracker launch (0 = default cap of 3072)
+// wavefronts of a wave-per-feature tracker launch (0 = default cap of 4096)
 extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
   if (!ctx || waves < 0) return GKLT_EINVAL;
   ctx->track_waves = waves;

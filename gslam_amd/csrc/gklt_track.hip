@@ -759,12 +759,12 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
     }
     for (int l = 0; l < P.nPyramidLevels; ++l)
       a.lv[l] = TrackLevel{nullptr, nullptr, py[0]->lv[l].w, py[0]->lv[l].h};
-    // Default cap: 3 wavefronts per SIMD (256 CUs x 4 SIMDs).  A launch that takes more of the
-    // chip's wave slots starves the pyramid build it overlaps with (measured at C2, lookahead 16:
-    // 3072 -> 160 M, 3584 -> 150 M, 4000 -> 141 M feature-frames/s; at C3 the uncapped 16000
-    // wavefronts serialise the two kernels).
-    // Single-frame launches are short and latency matters: one wavefront per feature.
-    const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? 3072 : n));
+    // Default cap for multi-frame launches: 4 wavefronts per SIMD (256 CUs x 4 SIMDs).  A launch
+    // that takes more of the chip's wave slots for the length of a whole batch starves the pyramid
+    // build it overlaps with (C3, 16000 features, lookahead 16: cap 4096 -> 117 M, 8192 -> 112 M,
+    // uncapped -> 106 M feature-frames/s).  Single-frame launches are short and latency matters:
+    // one wavefront per feature.
+    const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? 4096 : n));
     TrackFrames F{};
     F.nframes = nframes;
     for (int j = 0; j <= nframes; ++j)

@@ -160,7 +160,7 @@ class Context:
         _check(lib().gklt_ctx_set_track_impl(self.h, int(impl)))
 
     def set_track_waves(self, waves):
-        """wavefronts per tracker launch (0 = default cap of 3072)"""
+        """wavefronts per tracker launch (0 = default cap of 4096)"""
         _check(lib().gklt_ctx_set_track_waves(self.h, int(waves)))
 
     def set_pyramid_impl(self, impl):

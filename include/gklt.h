@@ -285,8 +285,8 @@ int gklt_device_synchronize(gklt_ctx *ctx);
  * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
 /* Wavefronts per wave-per-feature tracker launch; each takes features w, w + waves, ...  The
- * default (0) is one wavefront per feature for single-frame launches and a cap of 3072 wavefronts
- * (3 per SIMD) for the multi-frame launches of the lookahead pipeline, so that the
+ * default (0) is one wavefront per feature for single-frame launches and a cap of 4096 wavefronts
+ * (4 per SIMD) for the multi-frame launches of the lookahead pipeline, so that the
  * pyramid build it overlaps with always finds room.  Results do not depend on it. */
 int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
 /* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level) when the

@@ -173,7 +173,7 @@ def test_lookahead_argument_errors(klt, gpu_ctx):
 
 @pytest.mark.parametrize("waves", [1, 7, 64])
 def test_lookahead_wavefronts_take_several_features(klt, ok, gpu_ctx, waves):
-    """A multi-frame launch is capped at 3072 wavefronts; each takes features w, w + waves, ...
+    """A multi-frame launch is capped at 4096 wavefronts; each takes features w, w + waves, ...
     Forced here to a few wavefronts so that every one follows several features through the batch."""
     H, W, n = 135, 240, 150
     f = _stream(H, W, 5, seed=13)
