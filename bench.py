@@ -44,8 +44,8 @@ def _pmc_bytes(fetch_kib, write_kib, frames):
     return (2.0 * fetch_kib + write_kib) * 1024.0 / frames
 
 
-PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(143500.0, 1245.0, 16),
-               ("C2", "level0"): _pmc_bytes(90890.0, 550800.0, 16)}
+PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(167600.0, 1315.0, 16),
+               ("C2", "level0"): _pmc_bytes(76570.0, 550800.0, 16)}
 
 
 def parse():
