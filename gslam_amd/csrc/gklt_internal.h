@@ -67,6 +67,8 @@ struct gklt_ctx {
   // profiling
   int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
+  int sel_impl = 0;         // plain selector rounds: 0 = 32-bit keys, 1 = 64-bit keys
+  int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;
   struct Span {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_integral_cols(float *__restrict__ sxx,
 __global__ void k_score(const float *__restrict__ sxx, const float *__restrict__ syy,
                         const float *__restrict__ sxy, const unsigned char *__restrict__ blocked,
                         int w, int h, int hw, int hh, int bx, int by, int step, int min_eig,
-                        int round2, unsigned *__restrict__ state) {
+                        int round2, int score_max, unsigned *__restrict__ state) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= w) return;
   unsigned out = 0;
@@ -181,7 +181,9 @@ __global__ void k_score(const float *__restrict__ sxx, const float *__restrict__
       if (v > (float)min_eig) iv = v >= 2147483648.0f ? 0x7fffffff : (int)v;  // :351-361
     }
     // _enforceMinimumDistance only ever accepts val >= max(1, min_eigenvalue) (:103-104,175)
-    if (iv >= 1 && iv >= min_eig) out = (unsigned)iv;
+    // score_max: INT_MAX, or INT_MAX - 1 for the Uniform selector, where INT_MAX marks a surviving
+    // feature (:1132,1232) and the oracle documents the clamp one below it
+    if (iv >= 1 && iv >= min_eig) out = (unsigned)min(iv, score_max);
   }
   state[(size_t)y * w + x] = out;
 }
@@ -228,6 +230,7 @@ __device__ __forceinline__ void window_group(const unsigned long long *k, const 
   if (L2 >= G - 1) {
     unsigned long long cm = 0;
     unsigned co = 0;
+#pragma unroll
     for (int j = G - 1; j <= L2; ++j) {
       cm = max(cm, k[j * sk]);
       co |= a[j * sa];
@@ -267,30 +270,70 @@ __device__ __forceinline__ void window_group(const unsigned long long *k, const 
   }
 }
 
-// One fixpoint round on the 64x16 tile of this workgroup, shared by the plain and the Uniform
+// Fixpoint rounds on the 64x16 tile of this workgroup, shared by the plain and the Uniform
 // selector.  keyf(score, x, y) is the priority key of an undecided candidate; decide(gi, x, y,
-// own, covered, is_max) applies the round's rule to one undecided pixel and returns 1 if it stays
-// undecided.  The haloed tile (keys of undecided pixels, flags of accepted ones) is staged in
+// own, covered, is_max) applies the rule to one undecided pixel and returns kStays, kRejected or
+// kAcceptedNow.  The haloed tile (keys of undecided pixels, flags of accepted ones) is staged in
 // LDS, followed by a separable (2r+1)-window max of the keys / OR of the flags.
-template <typename KeyF, typename DecideF>
+//
+// One launch iterates the rule on the tile up to `max_local` times, with the halo as it was when
+// the tile was staged.  Decisions are final and never depend on information that can be
+// withdrawn (an accepted neighbour stays accepted; an undecided neighbour of higher priority only
+// makes the pixel wait), so a stale halo delays decisions but cannot change them: dependency
+// chains that stay inside a tile cost LDS iterations instead of launches.
+// `gate`: the tile is skipped when neither it nor one of its 8 neighbours decided anything in the
+// previous launch (prev_changed) -- it has already drawn every conclusion from that halo.
+constexpr int kStays = 1, kRejected = 0, kAcceptedNow = 2;
+// R >= 0: the radius as a compile-time constant (window loops unroll, their LDS reads are issued
+// together, staging divides by a constant); R < 0: radius r_rt.
+template <int R, typename KeyF, typename DecideF>
 __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ state, int w, int h,
-                                               int r, unsigned *__restrict__ counter,
-                                               unsigned *__restrict__ tile_left, KeyF keyf,
-                                               DecideF decide) {
+                                               int r_rt, unsigned *__restrict__ counter,
+                                               unsigned *__restrict__ tile_left,
+                                               const unsigned char *__restrict__ prev_changed,
+                                               unsigned char *__restrict__ cur_changed, int gate,
+                                               int max_local, KeyF keyf, DecideF decide) {
   extern __shared__ __align__(16) unsigned long long lds64[];
+  const int r = R >= 0 ? R : r_rt;
   const int inW = MW + 2 * r, inH = MH + 2 * r, S = mis_stride(r), SR = MW + 1;
   unsigned long long *key = lds64;          // inH x S  : key of undecided, 0 otherwise
   unsigned long long *rmax = key + inH * S; // inH x SR : row-window max
   unsigned char *acc = reinterpret_cast<unsigned char *>(rmax + inH * SR);  // inH x S accepted
   unsigned char *racc = acc + inH * S;                                      // inH x SR
   __shared__ int any_undecided;
-  __shared__ unsigned blk_left;
+  __shared__ unsigned blk_left[2];
+  __shared__ int blk_changed[2];
   const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
-  // tile_left = undecided core pixels after the tile's last round (all ones before the first):
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  // tile_left = undecided core pixels after the tile's last launch (all ones before the first):
   // a tile that has none left never gets any again and is skipped without staging
-  unsigned *const my_left = tile_left + blockIdx.y * gridDim.x + blockIdx.x;
-  if (*my_left == 0) return;
-  if (threadIdx.x == 0) { any_undecided = 0; blk_left = 0; }
+  unsigned *const my_left = tile_left + tile;
+  const unsigned left_before = *my_left;
+  if (left_before == 0) {
+    if (threadIdx.x == 0) cur_changed[tile] = 0;
+    return;
+  }
+  if (gate) {
+    int any = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int bx = (int)blockIdx.x + dx, by = (int)blockIdx.y + dy;
+        if (bx >= 0 && bx < (int)gridDim.x && by >= 0 && by < (int)gridDim.y)
+          any |= prev_changed[by * gridDim.x + bx];
+      }
+    if (!any) {  // uniform over the workgroup
+      if (threadIdx.x == 0) {
+        cur_changed[tile] = 0;
+        atomicAdd(counter, left_before);
+      }
+      return;
+    }
+  }
+  if (threadIdx.x == 0) {
+    any_undecided = 0;
+    blk_left[0] = blk_left[1] = 0;
+    blk_changed[0] = blk_changed[1] = 0;
+  }
   __syncthreads();
   // staging in batches of kStage unconditional (clamped) loads per thread, so that a batch is in
   // flight together instead of one load per round trip
@@ -324,59 +367,307 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
   if (mine) any_undecided = 1;
   __syncthreads();
   if (!any_undecided) {  // nothing to decide in this tile
-    if (threadIdx.x == 0) *my_left = 0;
+    if (threadIdx.x == 0) {
+      *my_left = 0;
+      cur_changed[tile] = 0;
+    }
     return;
   }
   constexpr int GR = 8, GC = 4;
-  // row pass: lane <-> row, 8 adjacent outputs per task
-  for (int t = threadIdx.x; t < inH * (MW / GR); t += MT) {
-    const int ty = t % inH, gq = t / inH;
-    unsigned long long m[GR];
-    unsigned o[GR];
-    window_group<GR>(key + ty * S + GR * gq, acc + ty * S + GR * gq, 1, 1, r, m, o);
+  int changed_ever = 0;
+  unsigned left_now = 0;
+  for (int it = 0; it < max_local; ++it) {
+    const int pp = it & 1;
+    // row pass: lane <-> row, 8 adjacent outputs per task
+    for (int t = threadIdx.x; t < inH * (MW / GR); t += MT) {
+      const int ty = t % inH, gq = t / inH;
+      unsigned long long m[GR];
+      unsigned o[GR];
+      window_group<GR>(key + ty * S + GR * gq, acc + ty * S + GR * gq, 1, 1, r, m, o);
 #pragma unroll
-    for (int i = 0; i < GR; ++i) {
-      rmax[ty * SR + GR * gq + i] = m[i];
-      racc[ty * SR + GR * gq + i] = (unsigned char)o[i];
+      for (int i = 0; i < GR; ++i) {
+        rmax[ty * SR + GR * gq + i] = m[i];
+        racc[ty * SR + GR * gq + i] = (unsigned char)o[i];
+      }
     }
-  }
-  __syncthreads();
-  // column pass: lane <-> column, 4 outputs (rows) per task
-  int left = 0;
-  for (int t = threadIdx.x; t < MW * (MH / GC); t += MT) {
-    const int tx = t % MW, gq = t / MW;
-    unsigned long long m[GC];
-    unsigned o[GC];
-    window_group<GC>(rmax + GC * gq * SR + tx, racc + GC * gq * SR + tx, SR, SR, r, m, o);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the other parity's slots: last read before this barrier, next
+      blk_left[pp ^ 1] = 0;  // written after the one that ends this iteration
+      blk_changed[pp ^ 1] = 0;
+    }
+    // column pass: lane <-> column, 4 outputs (rows) per task
+    int left = 0, changed = 0;
+    for (int t = threadIdx.x; t < MW * (MH / GC); t += MT) {
+      const int tx = t % MW, gq = t / MW;
+      unsigned long long m[GC];
+      unsigned o[GC];
+      window_group<GC>(rmax + GC * gq * SR + tx, racc + GC * gq * SR + tx, SR, SR, r, m, o);
 #pragma unroll
-    for (int i = 0; i < GC; ++i) {
-      const int ty = GC * gq + i;
-      const unsigned long long own = key[(ty + r) * S + tx + r];
-      if (own == 0) continue;
-      left += decide((size_t)(y0 + ty) * w + x0 + tx, x0 + tx, y0 + ty, own, o[i] != 0, m[i] == own);
+      for (int i = 0; i < GC; ++i) {
+        const int ty = GC * gq + i;
+        const int li = (ty + r) * S + tx + r;
+        const unsigned long long own = key[li];
+        if (own == 0) continue;
+        const int d = decide((size_t)(y0 + ty) * w + x0 + tx, x0 + tx, y0 + ty, own, o[i] != 0, m[i] == own);
+        if (d == kStays) {
+          ++left;
+        } else {  // only this thread reads or writes this pixel's own entry during the pass
+          key[li] = 0ull;
+          if (d == kAcceptedNow) acc[li] = 1;
+          changed = 1;
+        }
+      }
     }
+    if (left) atomicAdd(&blk_left[pp], (unsigned)left);
+    if (changed) blk_changed[pp] = 1;
+    __syncthreads();
+    left_now = blk_left[pp];
+    const int ch = blk_changed[pp];
+    changed_ever |= ch;
+    if (!ch || left_now == 0) break;
   }
-  if (left) atomicAdd(&blk_left, (unsigned)left);
-  __syncthreads();
   if (threadIdx.x == 0) {
-    *my_left = blk_left;
-    if (blk_left) atomicAdd(counter, blk_left);
+    *my_left = left_now;
+    cur_changed[tile] = (unsigned char)changed_ever;
+    if (left_now) atomicAdd(counter, left_now);
   }
 }
 
 // counters[round] = undecided candidates left after this round (summed over tiles)
+template <int R>
 __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
                                                   int r, unsigned *__restrict__ counters,
-                                                  unsigned *__restrict__ tile_left, int round) {
-  mis_round_tile(
-      state, w, h, r, counters + round, tile_left,
+                                                  unsigned *__restrict__ tile_left,
+                                                  const unsigned char *__restrict__ prev_changed,
+                                                  unsigned char *__restrict__ cur_changed,
+                                                  int gate, int max_local, int round) {
+  mis_round_tile<R>(
+      state, w, h, r, counters + round, tile_left, prev_changed, cur_changed, gate, max_local,
       [](unsigned s, int x, int y) { return prio_key(s, x, y); },
       [&](size_t gi, int, int, unsigned long long own, bool covered, bool is_max) -> int {
-        if (covered) state[gi] = 0;  // an accepted neighbour covers it
-        else if (is_max) state[gi] = (unsigned)(own >> 32) | kAccepted;
-        else return 1;
-        return 0;
+        if (covered) {  // an accepted neighbour covers it
+          state[gi] = 0;
+          return kRejected;
+        }
+        if (is_max) {
+          state[gi] = (unsigned)(own >> 32) | kAccepted;
+          return kAcceptedNow;
+        }
+        return kStays;
       });
+}
+
+// ---- the plain selector's rounds on 32-bit keys
+// The plain priority (score desc, y asc, x asc) needs no position bits in LDS: a tile keeps
+//   0            nothing to decide (no candidate, or rejected)
+//   score << 1   undecided candidate (score 1..INT_MAX)
+//   0xFFFFFFFF   accepted
+// and reduces windows with tie_max(a, b) = max(a, b) | (a == b): bit 0 of a window maximum says
+// that two or more entries share it.  A pixel whose score is the unique window maximum is the
+// highest-priority undecided one; a window maximum of 0xFFFFFFFF means an accepted neighbour.
+// Only when the top score is shared does the pixel compare positions, by scanning its window
+// (exact_window).  Two undecided INT_MAX scores would combine to 0xFFFFFFFF; a tile that stages
+// such a score decides all its pixels by scanning.  8 bytes of LDS per pixel instead of 18: all
+// tiles of a 1080p image are resident at once (8 workgroups per CU).
+inline size_t mis32_lds_bytes(int r) {
+  const size_t inH = MH + 2 * r;
+  return 4 * inH * (size_t)(mis_stride(r) + MW + 1);
+}
+__device__ __forceinline__ unsigned tie_max(unsigned a, unsigned b) {
+  return max(a, b) | (unsigned)(a == b);
+}
+// m[i] = tie_max over the window [i, i + 2r] of a strided sequence, for G consecutive i (see
+// window_group; the three parts of a window are disjoint, so no entry meets itself)
+template <int G>
+__device__ __forceinline__ void window_group32(const unsigned *k, int sk, int r, unsigned (&m)[G]) {
+  const int L2 = 2 * r;
+  if (L2 >= G - 1) {
+    unsigned cm = k[(G - 1) * sk];
+#pragma unroll
+    for (int j = G; j <= L2; ++j) cm = tie_max(cm, k[j * sk]);
+    m[G - 1] = cm;
+    unsigned sm = 0;
+#pragma unroll
+    for (int i = G - 2; i >= 0; --i) {
+      sm = i == G - 2 ? k[i * sk] : tie_max(sm, k[i * sk]);
+      m[i] = tie_max(cm, sm);
+    }
+    unsigned pm = 0;
+#pragma unroll
+    for (int i = 1; i < G; ++i) {
+      pm = i == 1 ? k[(L2 + 1) * sk] : tie_max(pm, k[(L2 + i) * sk]);
+      m[i] = tie_max(m[i], pm);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      unsigned mm = k[i * sk];
+      for (int j = 1; j <= L2; ++j) mm = tie_max(mm, k[(i + j) * sk]);
+      m[i] = mm;
+    }
+  }
+}
+// the rule for the undecided pixel at LDS index li by comparing it with every entry of its window
+__device__ __forceinline__ int exact_window(const unsigned *key, int li, int S, int r, unsigned own) {
+  bool covered = false, higher = false;
+  for (int dy = -r; dy <= r; ++dy)
+    for (int dx = -r; dx <= r; ++dx) {
+      const unsigned e = key[li + dy * S + dx];
+      covered |= e == 0xFFFFFFFFu;
+      higher |= e > own || (e == own && (dy < 0 || (dy == 0 && dx < 0)));
+    }
+  return covered ? kRejected : (higher ? kStays : kAcceptedNow);
+}
+
+template <int R>
+__global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state, int w, int h,
+                                                    int r_rt, unsigned *__restrict__ counters,
+                                                    unsigned *__restrict__ tile_left,
+                                                    const unsigned char *__restrict__ prev_changed,
+                                                    unsigned char *__restrict__ cur_changed,
+                                                    int gate, int max_local, int round) {
+  extern __shared__ __align__(16) unsigned lds32[];
+  const int r = R >= 0 ? R : r_rt;
+  const int inW = MW + 2 * r, inH = MH + 2 * r, S = mis_stride(r), SR = MW + 1;
+  unsigned *key = lds32;           // inH x S
+  unsigned *rmax = key + inH * S;  // inH x SR : row-window tie_max
+  __shared__ int any_undecided, scan_all;
+  __shared__ unsigned blk_left[2];
+  __shared__ int blk_changed[2];
+  unsigned *const counter = counters + round;
+  const int x0 = blockIdx.x * MW, y0 = blockIdx.y * MH;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  unsigned *const my_left = tile_left + tile;
+  const unsigned left_before = *my_left;
+  if (left_before == 0) {  // finished tiles stay finished
+    if (threadIdx.x == 0) cur_changed[tile] = 0;
+    return;
+  }
+  // the gate flags and the first staging batch are requested together
+  int any = gate ? 0 : 1;
+  if (gate) {
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int bx = min(max((int)blockIdx.x + dx, 0), (int)gridDim.x - 1);
+        const int by = min(max((int)blockIdx.y + dy, 0), (int)gridDim.y - 1);
+        any |= prev_changed[by * gridDim.x + bx];  // clamped: a tile of the neighbourhood again
+      }
+  }
+  constexpr int kStage = 12;
+  const int total = inW * inH;
+  unsigned sv[kStage];
+  int txv[kStage], tyv[kStage];
+#pragma unroll
+  for (int u = 0; u < kStage; ++u) {
+    const int i = min((int)threadIdx.x + u * MT, total - 1);
+    tyv[u] = i / inW;
+    txv[u] = i - tyv[u] * inW;
+    const int x = x0 - r + txv[u], y = y0 - r + tyv[u];
+    const unsigned v = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
+    sv[u] = (x >= 0 && x < w && y >= 0 && y < h) ? v : 0u;
+  }
+  if (!any) {  // uniform over the workgroup
+    if (threadIdx.x == 0) {
+      cur_changed[tile] = 0;
+      atomicAdd(counter, left_before);
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    any_undecided = 0;
+    scan_all = 0;
+    blk_left[0] = blk_left[1] = 0;
+    blk_changed[0] = blk_changed[1] = 0;
+  }
+  __syncthreads();
+  int mine = 0, intmax = 0;
+  auto put = [&](int tx, int ty, unsigned sval) {
+    const bool a = (sval & kAccepted) != 0;
+    key[ty * S + tx] = sval == 0 ? 0u : (a ? 0xFFFFFFFFu : sval << 1);
+    if (sval != 0 && !a) {
+      intmax |= sval == 0x7FFFFFFFu;
+      if (tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < kStage; ++u)
+    if ((int)threadIdx.x + u * MT < total) put(txv[u], tyv[u], sv[u]);
+  for (int i = threadIdx.x + kStage * MT; i < total; i += MT) {  // radii beyond 10
+    const int ty = i / inW, tx = i - ty * inW;
+    const int x = x0 - r + tx, y = y0 - r + ty;
+    put(tx, ty, (x >= 0 && x < w && y >= 0 && y < h) ? state[(size_t)y * w + x] : 0u);
+  }
+  if (mine) any_undecided = 1;
+  if (intmax) scan_all = 1;
+  __syncthreads();
+  if (!any_undecided) {
+    if (threadIdx.x == 0) {
+      *my_left = 0;
+      cur_changed[tile] = 0;
+    }
+    return;
+  }
+  const bool exact_all = scan_all != 0;
+  constexpr int GR = 8, GC = 4;
+  int changed_ever = 0;
+  unsigned left_now = 0;
+  for (int it = 0; it < max_local; ++it) {
+    const int pp = it & 1;
+    for (int t = threadIdx.x; t < inH * (MW / GR); t += MT) {  // row pass: lane <-> row
+      const int ty = t % inH, gq = t / inH;
+      unsigned m[GR];
+      window_group32<GR>(key + ty * S + GR * gq, 1, r, m);
+#pragma unroll
+      for (int i = 0; i < GR; ++i) rmax[ty * SR + GR * gq + i] = m[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // see mis_round_tile
+      blk_left[pp ^ 1] = 0;
+      blk_changed[pp ^ 1] = 0;
+    }
+    int left = 0, changed = 0;
+    for (int t = threadIdx.x; t < MW * (MH / GC); t += MT) {  // column pass: lane <-> column
+      const int tx = t % MW, gq = t / MW;
+      unsigned m[GC];
+      window_group32<GC>(rmax + GC * gq * SR + tx, SR, r, m);
+#pragma unroll
+      for (int i = 0; i < GC; ++i) {
+        const int ty = GC * gq + i;
+        const int li = (ty + r) * S + tx + r;
+        const unsigned own = key[li];
+        if (own == 0 || own == 0xFFFFFFFFu) continue;
+        int d;
+        if (exact_all) d = exact_window(key, li, S, r, own);
+        else if (m[i] == 0xFFFFFFFFu) d = kRejected;           // an accepted neighbour covers it
+        else if ((m[i] >> 1) != (own >> 1)) d = kStays;        // a higher score is undecided
+        else if (!(m[i] & 1)) d = kAcceptedNow;                // unique top score
+        else d = exact_window(key, li, S, r, own);             // top score shared: positions decide
+        if (d == kStays) {
+          ++left;
+          continue;
+        }
+        // exact_window of other threads may read this entry during the pass: they see the pixel
+        // undecided or decided, and either is a state the rule is safe on (see mis_round_tile)
+        key[li] = d == kAcceptedNow ? 0xFFFFFFFFu : 0u;
+        state[(size_t)(y0 + ty) * w + x0 + tx] = d == kAcceptedNow ? ((own >> 1) | kAccepted) : 0u;
+        changed = 1;
+      }
+    }
+    if (left) atomicAdd(&blk_left[pp], (unsigned)left);
+    if (changed) blk_changed[pp] = 1;
+    __syncthreads();
+    left_now = blk_left[pp];
+    const int ch = blk_changed[pp];
+    changed_ever |= ch;
+    if (!ch || left_now == 0) break;
+  }
+  if (threadIdx.x == 0) {
+    *my_left = left_now;
+    cur_changed[tile] = (unsigned char)changed_ever;
+    if (left_now) atomicAdd(counter, left_now);
+  }
 }
 
 // Appends the accepted pixels of a 256-column x 32-row block to a list, emit(i, x, y, score)
@@ -440,9 +731,14 @@ __global__ __launch_bounds__(256) void k_collect(const unsigned *__restrict__ st
 // before the launch).  The key range is split over gridDim.y so that ranking ~10^4 accepted
 // features is spread over the whole chip instead of 40 workgroups.
 constexpr int kRankSlices = 16;
+// n = min(*count, cap) is read on the device: the grid is sized for an upper bound and the host does
+// not wait for the count.
 __global__ __launch_bounds__(256) void k_rank_partial(const unsigned long long *__restrict__ keys,
-                                                      unsigned n, unsigned *__restrict__ rank) {
+                                                      const unsigned *__restrict__ count,
+                                                      unsigned cap, unsigned *__restrict__ rank) {
   __shared__ unsigned long long tile[256];
+  const unsigned n = min(*count, cap);
+  if (blockIdx.x * 256 >= n) return;
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
   const unsigned long long own = i < n ? keys[i] : 0ull;
   const unsigned per = ((n + gridDim.y - 1) / gridDim.y + 255) / 256 * 256;
@@ -491,13 +787,14 @@ __global__ void k_lost_slots(const int *__restrict__ fval, int n, int overwrite,
 
 // rank of each accepted key among all accepted keys (descending); rank < nslots -> slot[rank]
 __global__ __launch_bounds__(256) void k_assign(const unsigned long long *__restrict__ list,
-                                                const unsigned *__restrict__ ranks, unsigned n,
+                                                const unsigned *__restrict__ ranks,
+                                                const unsigned *__restrict__ count, unsigned cap,
                                                 const int *__restrict__ slots,
                                                 const int *__restrict__ nslots,
                                                 float *__restrict__ fx, float *__restrict__ fy,
                                                 int *__restrict__ fval) {
   const unsigned i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  if (i >= min(*count, cap)) return;
   const unsigned long long own = list[i];
   const unsigned rank = ranks[i];
   if ((int)rank < *nslots) {
@@ -535,6 +832,9 @@ struct SelScratch {
   unsigned *rank = nullptr;      // rank of list[i] among the accepted keys
   unsigned *tile_left = nullptr; // per 64x16 tile: undecided pixels after its last round
   size_t tile_bytes = 0;
+  unsigned char *tile_changed = nullptr;  // [2][ntiles]: tile decided something in launch k (slot k & 1)
+  size_t ntiles = 0;
+  int last_rounds[2] = {0, 0};  // launches of the last selection (Uniform: phase A, phase B)
   unsigned *counters = nullptr;  // [0] accepted count, [1..] per-round undecided
   int *slots = nullptr, *nslots = nullptr;
   unsigned *h_counters = nullptr;  // pinned
@@ -553,6 +853,7 @@ void sel_free(SelScratch *s) {
   (void)hipFree(s->list);
   (void)hipFree(s->rank);
   (void)hipFree(s->tile_left);
+  (void)hipFree(s->tile_changed);
   (void)hipFree(s->counters);
   (void)hipFree(s->slots);
   (void)hipFree(s->nslots);
@@ -583,6 +884,8 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
     GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * (size_t)s->cap_list));
     s->tile_bytes = sizeof(unsigned) * (size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH);
     GKLT_HIP(hipMalloc(&s->tile_left, s->tile_bytes));
+    s->ntiles = s->tile_bytes / sizeof(unsigned);
+    GKLT_HIP(hipMalloc(&s->tile_changed, 2 * s->ntiles));
     GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
     GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
     GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
@@ -635,7 +938,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
     ProfScope ps(ctx, s, GKLT_K_SELECT);
     hipLaunchKernelGGL(k_score, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->sum[0], sc->sum[1],
                        sc->sum[2], overwrite ? (const unsigned char *)nullptr : sc->blocked, w, h,
-                       hw, hh, bx, by, step, P.min_eigenvalue, round2, sc->state);
+                       hw, hh, bx, by, step, P.min_eigenvalue, round2, 0x7fffffff, sc->state);
   }
   hipLaunchKernelGGL(k_lost_slots, dim3(1), dim3(1024), 0, s, fval, n, overwrite, sc->slots,
                      sc->nslots);
@@ -643,32 +946,49 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
 
   // fixpoint rounds (r < 0 happens for mindist 0: every candidate is accepted in one round)
   const int rr = std::max(r, 0);
-  const size_t lds = mis_lds_bytes(rr);
+  // 32-bit keys by default; the 64-bit rounds shared with the Uniform selector stay selectable
+  const bool k32 = ctx->sel_impl == 0;
+  const size_t lds = k32 ? mis32_lds_bytes(rr) : mis_lds_bytes(rr);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", P.mindist, lds);
     return GKLT_EINVAL;
   }
+  // the radii of the reference's defaults (mindist 10: 9 plain, 10 for the ...2 / Uniform flavours)
+  // are compiled in; any other radius runs the same code with r at run time
+  auto kern = k32 ? (rr == 9 ? k_mis32_round<9> : rr == 10 ? k_mis32_round<10> : k_mis32_round<-1>)
+                  : (rr == 9 ? k_mis_round<9> : rr == 10 ? k_mis_round<10> : k_mis_round<-1>);
   if (lds > 48 * 1024)
-    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mis_round),
+    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH);
   GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));
+  GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
   int round = 1;
   bool done = false;
   while (!done) {
     const int first = round;
     {
       ProfScope ps(ctx, s, GKLT_K_SELECT);
-      for (int b = 0; b < kRoundBatch && round <= kMaxRounds; ++b, ++round)
-        hipLaunchKernelGGL(k_mis_round, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
-                           sc->tile_left, round);
+      // first batch: what the previous selection on this context needed plus a margin (video:
+      // the count hardly changes from frame to frame); a converged launch costs ~4 us, a sync ~25
+      const int nbatch = first == 1 && sc->last_rounds[0] > 0
+                             ? std::min(std::max(sc->last_rounds[0] + 2, 4), kRoundBatch) : kRoundBatch;
+      for (int b = 0; b < nbatch && round <= kMaxRounds; ++b, ++round)
+        hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
+                           sc->tile_left, sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
+                           sc->tile_changed + (round & 1) * sc->ntiles, 1, ctx->sel_local_iters,
+                           round);
     }
     GKLT_HIP(hipGetLastError());
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
                             sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
-    for (int k = first; k < round; ++k)
-      if (sc->h_counters[k] == 0) done = true;
+    for (int k = first; k < round && !done; ++k)
+      if (sc->h_counters[k] == 0) {
+        done = true;
+        sc->last_rounds[0] = k;
+        sc->last_rounds[1] = 0;
+      }
     if (!done && round > kMaxRounds) {
       set_error("min-distance suppression did not converge in %d rounds", kMaxRounds);
       return GKLT_EHIP;
@@ -679,26 +999,21 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
     hipLaunchKernelGGL(k_collect, collect_grid(w, h), dim3(256), 0, s, sc->state, w, h, sc->list,
                        sc->counters, (unsigned)sc->cap_list);
   }
-  GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  GKLT_HIP(hipStreamSynchronize(s));
-  const unsigned naccepted = std::min(sc->h_counters[0], (unsigned)sc->cap_list);
-  if (sc->h_counters[0] > (unsigned)sc->cap_list) {
-    set_error("accepted-feature list overflow (%u > %d)", sc->h_counters[0], sc->cap_list);
-    return GKLT_ECAPACITY;
-  }
+  // accepted features are more than r apart in x or in y: at most one per (r+1) x (r+1) block.
+  // Ranking and slot assignment are sized for that bound and read the count on the device.
+  const unsigned nbound = (unsigned)std::min<long long>(
+      sc->cap_list, (long long)((w + rr) / (rr + 1)) * ((h + rr) / (rr + 1)));
   {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    if (naccepted > 0) {
-      const unsigned nb = (naccepted + 255) / 256;
-      GKLT_HIP(hipMemsetAsync(sc->rank, 0, sizeof(unsigned) * naccepted, s));
-      hipLaunchKernelGGL(k_rank_partial, dim3(nb, kRankSlices), dim3(256), 0, s, sc->list,
-                         naccepted, sc->rank);
-      hipLaunchKernelGGL(k_assign, dim3(nb), dim3(256), 0, s, sc->list, sc->rank, naccepted,
-                         sc->slots, sc->nslots, fx, fy, fval);
-    }
+    const unsigned nb = (nbound + 255) / 256;
+    GKLT_HIP(hipMemsetAsync(sc->rank, 0, sizeof(unsigned) * nbound, s));
+    hipLaunchKernelGGL(k_rank_partial, dim3(nb, kRankSlices), dim3(256), 0, s, sc->list,
+                       sc->counters, nbound, sc->rank);
+    hipLaunchKernelGGL(k_assign, dim3(nb), dim3(256), 0, s, sc->list, sc->rank, sc->counters,
+                       nbound, sc->slots, sc->nslots, fx, fy, fval);
     if (n > 0)
       hipLaunchKernelGGL(k_fill_rest, dim3((n + 255) / 256), dim3(256), 0, s, sc->counters,
-                         (unsigned)sc->cap_list, sc->slots, sc->nslots, fx, fy, fval);
+                         nbound, sc->slots, sc->nslots, fx, fy, fval);
   }
   GKLT_HIP(hipGetLastError());
   return 0;
@@ -756,33 +1071,41 @@ __global__ void k_u_cellmax(const unsigned *__restrict__ state, int w, int h, UG
   if (s != 0 && !(s & kAccepted)) atomicMax(&cellmax[ucell(x, y, g)], ukey(s, x, y, g));
 }
 
+template <int R>
 __global__ __launch_bounds__(MT) void k_u_round(unsigned *__restrict__ state, int w, int h, int r,
                                                 UGrid g, UCaps caps,
                                                 unsigned *__restrict__ counters,
-                                                unsigned *__restrict__ tile_left, int round) {
-  mis_round_tile(
-      state, w, h, r, counters + round, tile_left,
+                                                unsigned *__restrict__ tile_left,
+                                                const unsigned char *__restrict__ prev_changed,
+                                                unsigned char *__restrict__ cur_changed, int gate,
+                                                int max_local, int round) {
+  mis_round_tile<R>(
+      state, w, h, r, counters + round, tile_left, prev_changed, cur_changed, gate, max_local,
       [&](unsigned s, int x, int y) { return ukey(s, x, y, g); },
       [&](size_t gi, int x, int y, unsigned long long own, bool covered, bool is_max) -> int {
         const unsigned val = (unsigned)((own >> 16) & 0x7fffffffu);
         if (covered) {
           state[gi] = 0;
-        } else if (!caps.enabled) {
-          if (is_max) state[gi] = val | kAccepted; else return 1;
-        } else {
-          const int c = ucell(x, y, g);
-          const int rk = 0xFFFF - (int)(own >> 48);
-          const int cap = rk < caps.rankT ? 0x7fffffff : (rk == caps.rankT ? caps.capT : caps.capAfter);
-          if (caps.cellcount[c] >= cap) {
-            state[gi] = 0;                       // the cell is full (:1253-1254)
-          } else if (is_max && caps.cellmax[c] == own) {
-            state[gi] = val | kAccepted;
-            atomicAdd(&caps.cellcount[c], 1);
-          } else {
-            return 1;
-          }
+          return kRejected;
         }
-        return 0;
+        if (!caps.enabled) {
+          if (!is_max) return kStays;
+          state[gi] = val | kAccepted;
+          return kAcceptedNow;
+        }
+        const int c = ucell(x, y, g);
+        const int rk = 0xFFFF - (int)(own >> 48);
+        const int cap = rk < caps.rankT ? 0x7fffffff : (rk == caps.rankT ? caps.capT : caps.capAfter);
+        if (caps.cellcount[c] >= cap) {
+          state[gi] = 0;  // the cell is full (:1253-1254)
+          return kRejected;
+        }
+        if (is_max && caps.cellmax[c] == own) {
+          state[gi] = val | kAccepted;
+          atomicAdd(&caps.cellcount[c], 1);
+          return kAcceptedNow;
+        }
+        return kStays;
       });
 }
 
@@ -912,11 +1235,16 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", r, lds);
     return GKLT_EINVAL;
   }
+  auto kern = r == 10 ? k_u_round<10> : k_u_round<-1>;
   if (lds > 48 * 1024)
-    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_u_round),
+    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH), pgrid((w + 255) / 256, h);
   GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));  // a phase starts: all tiles live
+  GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
+  // with caps a decision also depends on the cell's counters and maximum, which change without
+  // any tile of the neighbourhood changing: no gating there
+  const int gate = caps.enabled ? 0 : 1;
   int round = *round_io;
   bool done = false;
   while (!done) {
@@ -928,16 +1256,22 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
           GKLT_HIP(hipMemsetAsync(u->cellmax, 0, sizeof(unsigned long long) * u->ncell, s));
           hipLaunchKernelGGL(k_u_cellmax, pgrid, dim3(256), 0, s, sc->state, w, h, g, u->cellmax);
         }
-        hipLaunchKernelGGL(k_u_round, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps,
-                           sc->counters, sc->tile_left, round);
+        hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps,
+                           sc->counters, sc->tile_left,
+                           sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
+                           sc->tile_changed + (round & 1) * sc->ntiles, gate, ctx->sel_local_iters,
+                           round);
       }
     }
     GKLT_HIP(hipGetLastError());
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
                             sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
-    for (int k = first; k < round; ++k)
-      if (sc->h_counters[k] == 0) done = true;
+    for (int k = first; k < round && !done; ++k)
+      if (sc->h_counters[k] == 0) {
+        done = true;
+        sc->last_rounds[caps.enabled ? 1 : 0] = k;
+      }
     if (!done && round > kMaxRounds) {
       set_error("uniform selection did not converge in %d rounds", kMaxRounds);
       return GKLT_EHIP;
@@ -995,7 +1329,7 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     ProfScope ps(ctx, s, GKLT_K_SELECT);
     hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->sum[0], sc->sum[1], sc->sum[2],
                        (const unsigned char *)nullptr, w, h, hw, hh, bx, by, step,
-                       P.min_eigenvalue, 0, sc->state);
+                       P.min_eigenvalue, 0, 0x7ffffffe, sc->state);
   }
   GKLT_HIP(hipMemcpyAsync(u->state0, sc->state, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
 
@@ -1017,7 +1351,7 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     if (*n_acc) {
       GKLT_HIP(hipMemsetAsync(u->rank, 0, sizeof(unsigned) * *n_acc, s));
       hipLaunchKernelGGL(k_rank_partial, dim3((*n_acc + 255) / 256, kRankSlices), dim3(256), 0, s,
-                         sc->list, *n_acc, u->rank);
+                         sc->list, sc->counters, *n_acc, u->rank);
     }
     GKLT_HIP(hipGetLastError());
     return 0;
@@ -1091,6 +1425,25 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
 using namespace gklt;
 
 // ============================================================================ C ABI
+extern "C" int gklt_ctx_set_select_iters(gklt_ctx *ctx, int iters) {
+  if (!ctx || iters < 1 || iters > 64) return GKLT_EINVAL;
+  ctx->sel_local_iters = iters;
+  return 0;
+}
+
+extern "C" int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl) {
+  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  ctx->sel_impl = impl;
+  return 0;
+}
+
+extern "C" int gklt_ctx_select_rounds(gklt_ctx *ctx, int rounds[2]) {
+  if (!ctx || !rounds) return GKLT_EINVAL;
+  rounds[0] = ctx->sel ? ctx->sel->last_rounds[0] : 0;
+  rounds[1] = ctx->sel ? ctx->sel->last_rounds[1] : 0;
+  return 0;
+}
+
 extern "C" int gklt_integral_products(gklt_ctx *ctx, gklt_pyramid *py, float *sumxx, float *sumyy,
                                       float *sumxy) {
   if (!ctx || !py || py->ctx != ctx || !sumxx || !sumyy || !sumxy) return GKLT_EINVAL;

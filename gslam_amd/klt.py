@@ -159,6 +159,20 @@ class Context:
         """0 = one feature per wavefront (default), 1 = one feature per 8-lane slice."""
         _check(lib().gklt_ctx_set_track_impl(self.h, int(impl)))
 
+    def set_select_impl(self, impl):
+        """Plain selector rounds: 0 = 32-bit keys (default), 1 = 64-bit keys."""
+        _check(lib().gklt_ctx_set_select_impl(self.h, int(impl)))
+
+    def set_select_iters(self, iters):
+        """Fixpoint iterations per tile and suppression launch of the selector (default 3)."""
+        _check(lib().gklt_ctx_set_select_iters(self.h, int(iters)))
+
+    def select_rounds(self):
+        """Suppression launches of the last selection: (plain or Uniform phase A, Uniform phase B)."""
+        r = (C.c_int * 2)()
+        _check(lib().gklt_ctx_select_rounds(self.h, r))
+        return int(r[0]), int(r[1])
+
     def set_track_waves(self, waves):
         """wavefronts per tracker launch (0 = default cap of 4096)"""
         _check(lib().gklt_ctx_set_track_waves(self.h, int(waves)))

@@ -293,7 +293,16 @@ int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
  * kernel radii are the reference's defaults, separate kernels otherwise (default); 1 = always
  * the separate smooth / decimate / gradient kernels.  Identical results. */
 int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
-
+/* Plain / ...2 selector rounds: 0 = 32-bit keys in LDS (default), 1 = the 64-bit-key rounds the
+ * Uniform selector uses.  Identical results. */
+int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl);
+/* Selector: fixpoint iterations a tile runs in LDS per suppression launch (1..64, default 3;
+ * 1 = one iteration per launch).  Results do not depend on it. */
+int gklt_ctx_set_select_iters(gklt_ctx *ctx, int iters);
+/* Suppression launches the last selection on this context needed until no candidate was left
+ * undecided: rounds[0] = plain / ...2 selector or phase A (no per-cell caps) of the Uniform
+ * one, rounds[1] = phase B of the Uniform one (0 otherwise). */
+int gklt_ctx_select_rounds(gklt_ctx *ctx, int rounds[2]);
 
 enum {
   GKLT_K_SMOOTH0 = 0, /* u8 -> smoothed level 0 */

@@ -180,3 +180,52 @@ def test_full_size_1080p_select(klt, ok, gpu_ctx):
     ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, n, grid=(32, 32))
     _same_lists(got, ref)
     assert len(got[2]) > n
+
+
+def _checker_gradients(H, W, amp):
+    """gx on even, gy on odd pixels: the 2x2 matrix of a window is ~diagonal, lambda_min ~ 24 amp^2."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    even = ((xx + yy) & 1) == 0
+    amp = np.broadcast_to(np.asarray(amp, np.float32), (H, W))
+    return np.where(even, amp, 0).astype(np.float32), np.where(even, 0, amp).astype(np.float32)
+
+
+@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 6), (0, 64), (1, 1), (1, 6)])
+@pytest.mark.parametrize("case", ["texture", "saturated", "flat_ties"])
+def test_select_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case):
+    """32-bit and 64-bit rounds, any number of LDS iterations per launch: the same lists.
+    saturated: a block of INT_MAX scores (clamped, selectGoodFeatures.hpp:351-361) next to ordinary
+    ones; flat_ties: every candidate has the same score, so positions alone decide."""
+    H, W, n = 120, 200, 300
+    kw = dict(window=7, levels=2, border=6, mindist=10, min_eigenvalue=50)
+    if case == "texture":
+        _, sums = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    else:
+        rng = np.random.default_rng(11)
+        if case == "saturated":
+            amp = rng.uniform(2.0, 40.0, (H, W)).astype(np.float32)
+            amp[30:80, 50:150] = 20000.0
+        else:
+            amp = np.float32(8.0)
+        sums = ok.integral_products(*_checker_gradients(H, W, amp))
+    gpu_ctx.set_params(klt.make_params(**kw))
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_PLAIN, *sums, n)
+    gpu_ctx.set_select_impl(impl)
+    gpu_ctx.set_select_iters(iters)
+    try:
+        got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_PLAIN, *sums, n)
+        rounds = gpu_ctx.select_rounds()
+        gotu = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *sums, 40, grid=(32, 32),
+                                   capacity=4096)
+    finally:
+        gpu_ctx.set_select_impl(0)
+        gpu_ctx.set_select_iters(3)
+    _same_lists(got, ref)
+    assert rounds[0] >= 1 and rounds[1] == 0
+    if case == "saturated":
+        assert (got[2] == 0x7fffffff).sum() >= 8
+    if case == "flat_ties":
+        assert len(np.unique(got[2][got[2] > 0])) <= 3
+    refu = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, 40, grid=(32, 32),
+                              capacity=4096)
+    _same_lists(gotu, refu)

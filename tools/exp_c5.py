@@ -13,6 +13,8 @@ cfg = dict(synth.CONFIGS["C2"]); H, W, n = cfg["H"], cfg["W"], cfg["n"]
 gp = klt.make_params(window=7, levels=4, min_eigenvalue=100, mindist=10)
 gp.bordery = max(gp.bordery, 24)
 ctx = klt.Context(0, gp)
+if len(sys.argv) > 2:
+    ctx.set_select_iters(int(sys.argv[2]))
 frames = synth.make_stream(H, W, 16)
 ptrs = [ctx.device_upload(f) for f in frames]
 ring = [klt.Pyramid(ctx, W, H) for _ in range(3)]
@@ -42,6 +44,7 @@ run(32, 16 + K)
 prof = ctx.profile_get(); ctx.profile_enable(False)
 print("C5: %.1f frames/s, %.2f ms/frame, tracked/frame %.0f, list size %d, %.2fM tracked features*frames/s" % (
     K / dt, dt / K * 1e3, tracked / K, len(fl), tracked / dt / 1e6))
+print("    suppression launches of the last selection (phase A, phase B):", ctx.select_rounds())
 print("    per frame (us):", {k: round(ms / 32 * 1e3, 1) for k, (ms, c) in prof.items() if c})
 for p in ring:
     p.close()
