@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--frames", type=int, default=64, help="distinct synthetic frames (looped)")
     ap.add_argument("--lookahead", type=int, default=16,
                     help="frames per gklt_lookahead_submit (0 = gklt_pipeline_step, frame at a time)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="BASELINE config 4: this many independent streams IN TOTAL, sharded over the ranks "
+                         "(streams/gpus per GPU, stepped together through gklt_multistream, one frame of "
+                         "each per call, no lookahead); a step is then one frame of every stream")
     ap.add_argument("--track-waves", type=int, default=0, help="wavefronts per tracker launch (0 = library default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
@@ -245,6 +249,173 @@ def rank_seed(rank):
     return synth.BASE_SEED + 1000 * rank
 
 
+def shard_streams(total, world, rank):
+    """Config 4 partition: stream s -> rank s mod world.  Returns this rank's stream ids."""
+    return [s for s in range(total) if s % world == rank]
+
+
+class MultiStreamSet:
+    """This rank's share of the config-4 streams behind one gklt_multistream.  To bound host-side
+    generation time the rank renders at most 4 distinct synthetic sequences; stream s plays
+    sequence s mod 4 from phase 5*s (frames are read-only in HBM, so streams share the copies).
+    Every stream has its own pyramid ring and feature list and does the full per-frame work."""
+
+    NSEQ = 4
+
+    def __init__(self, ctx, cfg, ids, nframes, gp):
+        H, W, n = cfg["H"], cfg["W"], cfg["n"]
+        self.ctx, self.cfg, self.ids, self.S, self.nf = ctx, cfg, ids, len(ids), nframes
+        self.ms = klt.MultiStream(ctx, self.S, W, H, n)
+        self.seq = {}
+        for s in ids:
+            q = s % self.NSEQ
+            if q not in self.seq:
+                fr = synth.make_stream(H, W, nframes, seed=rank_seed(q))
+                self.seq[q] = [ctx.device_upload(f) for f in fr]
+        sx, sy = synth.lattice_seeds(H, W, n, gp.borderx, seed=synth.BASE_SEED,
+                                     nx=cfg["lattice"][0], ny=cfg["lattice"][1])
+        self.seeds = (sx, sy, np.zeros(len(sx), np.int32))
+        self.host = [ctx.pinned_array((3, self.S * n), np.float32) for _ in range(4)]
+        self.t = 0
+
+    def frames(self, t):
+        W = self.cfg["W"]
+        return [(self.seq[s % self.NSEQ][(t + 5 * s) % self.nf], W) for s in self.ids]
+
+    def seed(self):
+        for i in range(self.S):
+            self.ms.upload_features(i, *self.seeds)
+
+    def start(self):
+        self.seed()
+        self.ms.start(self.frames(0), self.frames(1))
+        self.t = 1
+
+    def step(self):
+        t = self.t
+        if t % RESEED_EVERY == 0:
+            self.seed()
+        self.ms.step(self.frames(t + 1), self.host[t % 4][1])
+        self.t = t + 1
+
+    def run(self, k):
+        for _ in range(k):
+            self.step()
+
+    def sync(self):
+        self.ms.sync()
+
+    def close(self):
+        self.ms.close()
+        for fr in self.seq.values():
+            for p in fr:
+                self.ctx.device_free(p)
+        for _, p in self.host:
+            self.ctx.pinned_free(p)
+
+
+def main_multistream(a, ctx, cfg, gp, dist, rank, world):
+    """--streams S: S streams in total, S/world per GPU, one frame of each per step."""
+    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    ids = shard_streams(a.streams, world, rank)
+    if not ids:
+        raise SystemExit("--streams must be at least the number of GPUs")
+    st = MultiStreamSet(ctx, cfg, ids, min(a.frames, 16), gp)
+    st.start()
+    steps, warm = a.steps, a.warmup
+
+    def barrier():
+        ctx.device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    st.run(warm)
+    st.sync()
+    st.ms.stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    st.run(steps)
+    st.sync()
+    ctx.device_synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    tracked, iters = st.ms.stats(reset=True)
+    dt_max, tracked_all, iters_all = reduce_over_ranks(dist, dt, tracked, iters)
+
+    psteps = min(steps, 64)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    st.run(psteps)
+    st.sync()
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    p_tracked, p_iters = st.ms.stats(reset=True)
+    lat = []
+    for _ in range(min(steps, 64)):
+        q0 = time.perf_counter()
+        st.step()
+        st.ms.wait_tracked()
+        lat.append((time.perf_counter() - q0) * 1e3)
+        st.sync()
+    lat = np.array(lat)
+
+    b_pyr, foot, px = algorithmic_bytes(cfg)
+    S = len(ids)
+    per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}
+                  for k, (ms, cnt) in prof.items() if cnt}
+    fpl0 = min(S, 16)  # frames per level launch (streams beyond 16 take further launches)
+    alg_by_kernel = {
+        "track": (4.0 * n * cfg["levels"] * S + 3.0 * p_iters / psteps) * foot,
+        "level0": W * H * (1 + 12 + 1.0) * S * psteps / max(per_kernel.get("level0", {}).get("launches", 1), 1),
+    }
+    dom = max((k for k in per_kernel if k in alg_by_kernel), key=lambda k: per_kernel[k]["total_ms"])
+    alg = alg_by_kernel[dom]
+    achieved = alg / (per_kernel[dom]["avg_us"] * 1e-6) / 1e9
+    names = {"track": "k_track_w", "level0": "k_level<u8>"}
+    out = {
+        "metric": "tracked features*frames/sec at 1080p, 4000 pts, 4-level pyramid; per-frame latency",
+        "value": tracked_all / dt_max,
+        "unit": "tracked_features*frames/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warm,
+        "ms_per_step": dt_max / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "C4: %d independent streams of %s (%dx%d u8, %d features, %d-level pyramid, "
+                               "%dx%d window) sharded stream s -> GPU s mod %d, %d per GPU, one frame of "
+                               "every stream per step (no lookahead)" % (
+                                   a.streams, a.config, W, H, n, cfg["levels"], cfg["window"], cfg["window"],
+                                   world, S),
+                   "streams": a.streams, "streams_per_gpu": S,
+                   "frames_per_s": a.streams * steps / dt_max,
+                   "tracked_fraction": tracked_all / (a.streams * steps * n),
+                   "newton_iters_per_feature_frame": iters_all / (a.streams * steps * n),
+                   "launch": "gklt_multistream: one launch per pyramid level per 16 streams, one tracker "
+                             "launch for all lists, build(t+1) || track(t)",
+                   "sequences": "each rank renders %d distinct sequences; stream s plays sequence s mod %d "
+                                "from phase 5*s" % (len(st.seq), MultiStreamSet.NSEQ),
+                   "parallelism": "stream-sharded x%d, no collective" % world},
+        "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                       "mode": "gklt_multistream_step call -> the lists of all of the rank's streams in pinned "
+                               "host memory (rank 0)"},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg, "avg_launch_us": per_kernel[dom]["avg_us"],
+                     "frames_per_launch": fpl0 if dom == "level0" else S},
+        "kernels": per_kernel,
+    }
+    st.close()
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -263,6 +434,8 @@ def main():
     gp = klt.make_params(**params_kw)
     ctx = klt.Context(0 if a.share_gpu else local_rank, gp)
     ctx.set_track_waves(a.track_waves)
+    if a.streams > 0:
+        return main_multistream(a, ctx, cfg, gp, dist, rank, world)
 
     seed = rank_seed(rank)
     frames = synth.make_stream(H, W, a.frames, seed=seed)

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgklt.so")
-SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip", "gklt_lookahead.hip", "gklt_bearing.hip",
+SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip", "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip",
            "gklt_select.hip"]
 HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h")]
 

@@ -147,6 +147,10 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
                         int n, float *x, float *y, int *val, const double *d_invk, double *d_norm,
                         double *d_vec, unsigned long long *stats, float *const *mirrors,
                         int mirror_stride);
+int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, int nstreams,
+                         int slot1, int slot2, int cap, const int *n, const gklt_pyramid *py0,
+                         float *x, float *y, int *val, unsigned long long *stats, float *mirror,
+                         int mirror_stride);
 // bearing vectors (gklt_bearing.hip); grows ctx->d_norm / d_vec to n entries (gklt_api.hip)
 int ensure_bearing_buffers(gklt_ctx *ctx, int n);
 // all launches of one pyramid build on stream s (gklt_api.hip)

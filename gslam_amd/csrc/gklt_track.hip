@@ -53,6 +53,16 @@ struct TrackFrames {
   int nframes;
 };
 
+// Multi-stream launches (gklt_multistream): one launch tracks the lists of several independent
+// video streams, each between its own pair of pyramids.  The texel planes of every stream's ring
+// slots sit in a device table that never changes; a launch names the two slots.  Stream s owns
+// list entries [s * cap, s * cap + n[s]).
+struct TrackStreams {
+  const Texel *const *tab;  // device: [nstreams][3][GKLT_MAX_LEVELS]
+  int nstreams, slot1, slot2, cap, nmax;
+  int n[GKLT_MAX_STREAMS];
+};
+
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
 constexpr int kStatShards = GKLT_STAT_SHARDS;
 
@@ -377,8 +387,9 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // FPL = footprint texels per lane (0 = no staging).
 // NEC = elements per AVX-lane chain when known at compile time (7x7: 7, 11x11: 16, 21x21: 56;
 // 0 = run time): the chain sums then unroll into NEC reads followed by NEC ordered adds.
-template <int EPL, int FPL, int NEC = 0>
-__global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
+// MS: multi-stream launch (TrackStreams M names the pyramids and list segments, F.nframes == 1).
+template <int EPL, int FPL, int NEC = 0, bool MS = false>
+__global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, TrackStreams M,
                                                 float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
                                                 const double *__restrict__ invk,
@@ -485,10 +496,18 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
   // and every XCD works on one contiguous eighth of the list.  Lists are spatially ordered in
   // practice (selection order, lattice seeds): neighbouring features, whose windows overlap at
   // the coarse levels, then share an L2.
-  const int per_xcd = (a.n + 7) >> 3;
-  for (int q = blockIdx.x; q < 8 * per_xcd; q += gridDim.x) {
-  const int f = (q & 7) * per_xcd + (q >> 3);
-  if (f >= a.n) continue;
+  // Multi-stream launches run the same slot order stream after stream (8 * per_xcd slots each, so
+  // q % 8 is still the XCD).
+  const int per_xcd = ((MS ? M.nmax : a.n) + 7) >> 3;
+  const int qs = 8 * per_xcd;
+  for (int q = blockIdx.x; q < (MS ? M.nstreams * qs : qs); q += gridDim.x) {
+  const int sidx = MS ? q / qs : 0;
+  const int ql = q - sidx * qs;
+  const int fl = (ql & 7) * per_xcd + (ql >> 3);
+  if (fl >= (MS ? M.n[sidx] : a.n)) continue;
+  const int f = MS ? sidx * M.cap + fl : fl;
+  const Texel *const *const tab1 = MS ? M.tab + (size_t)(sidx * 3 + M.slot1) * GKLT_MAX_LEVELS : nullptr;
+  const Texel *const *const tab2 = MS ? M.tab + (size_t)(sidx * 3 + M.slot2) * GKLT_MAX_LEVELS : nullptr;
   const int val0 = fval[f];
   float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
   int vcur = val0;
@@ -519,7 +538,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F,
     xo *= a.ss; yo *= a.ss;
     // ---- _trackFeature, LK.hpp:413-669 ----
     const int nc = a.lv[r].nc, nr = a.lv[r].nr;
-    const Texel *const lt1 = F.tex[fr][r], *const lt2 = F.tex[fr + 1][r];
+    const Texel *const lt1 = MS ? tab1[r] : F.tex[fr][r];
+    const Texel *const lt2 = MS ? tab2[r] : F.tex[fr + 1][r];
     int status = GKLT_TRACKED, iteration = 0;
     const float x1 = xloc, y1 = yloc;
     float x2 = xo, y2 = yo;
@@ -702,6 +722,138 @@ int launch_track(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *p1, const gkl
                              mirror_stride);
 }
 
+namespace {
+
+void fill_args(const gklt_params &P, const gklt_pyramid *py0, int n, bool epilogue,
+               int mirror_stride, TrackArgs *out) {
+  TrackArgs a{};
+  a.nlevels = P.nPyramidLevels;
+  a.ss = (float)P.subsampling;  // LK.hpp:978
+  a.inv_ss = (P.subsampling & (P.subsampling - 1)) == 0 ? 1.0f / (float)P.subsampling : 0.f;
+  a.ww = P.window_width;
+  a.wh = P.window_height;
+  a.step_factor = P.step_factor;
+  a.min_det = P.min_determinant;
+  a.min_disp = P.min_displacement;
+  a.max_residue = P.max_residue;
+  a.max_iter = P.max_iterations;
+  a.w0 = py0->lv[0].w;
+  a.h0 = py0->lv[0].h;
+  a.borderx = P.borderx;
+  a.bordery = P.bordery;
+  a.n = n;
+  a.do_epilogue = epilogue;
+  a.mirror_stride = mirror_stride;
+  for (int l = 0; l < P.nPyramidLevels; ++l)
+    a.lv[l] = TrackLevel{nullptr, nullptr, py0->lv[l].w, py0->lv[l].h};
+  *out = a;
+}
+
+struct WaveGeom {
+  int NA, NF, epl, fpl;
+  bool stage, fits;
+  size_t lds;
+};
+
+WaveGeom wave_geom(const gklt_ctx *ctx, int ww, int wh) {
+  WaveGeom g;
+  g.NA = 8 * ((ww * wh + 8) / 8);
+  g.NF = (ww + 1) * (wh + 1);
+  // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
+  // 19.2 us at C2, 11x11 86 / 98 us at C3, 21x21 67 / 39 us at Cship); track_impl 2 / 3 force it.
+  g.stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && ww * wh >= 200);
+  g.epl = (g.NA + 63) / 64;
+  g.fpl = (g.NF + 63) / 64;
+  g.lds = sizeof(float) * (size_t)(5 * g.NA + 40) + (g.stage ? sizeof(float4) * (size_t)g.NF : 0);
+  g.fits = g.epl <= 16 && g.fpl <= 16 && g.lds <= 48 * 1024;
+  return g;
+}
+
+// picks the instantiation of the wave-per-feature kernel for the window
+template <bool MS>
+void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a,
+                const TrackFrames &F, const TrackStreams &M, float *x, float *y, int *val,
+                const double *d_invk, double *d_norm, double *d_vec, unsigned long long *stats) {
+  const dim3 block(64);
+  const size_t wlds = g.lds;
+  const int epl = g.epl, fpl = g.fpl;
+#define GKLT_TRACK_W(E, FP, NE)                                                                 \
+  hipLaunchKernelGGL((k_track_w<E, FP, NE, MS>), dim3(nwaves), block, wlds, s, a, F, M, x, y, val, \
+                     d_invk, d_norm, d_vec, stats)
+  const int nec = g.NA / 8;
+  if (!g.stage) {
+    if (epl <= 1 && nec == 7) GKLT_TRACK_W(1, 0, 7);  // 7x7
+    else if (epl <= 1) GKLT_TRACK_W(1, 0, 0);
+    else if (epl <= 2 && nec == 16) GKLT_TRACK_W(2, 0, 16);  // 11x11
+    else if (epl <= 2) GKLT_TRACK_W(2, 0, 0);
+    else if (epl <= 4) GKLT_TRACK_W(4, 0, 0);
+    else if (epl <= 8) GKLT_TRACK_W(8, 0, 0);
+    else GKLT_TRACK_W(16, 0, 0);
+  } else if (epl <= 1) {
+    if (fpl <= 1) GKLT_TRACK_W(1, 1, 0); else GKLT_TRACK_W(1, 2, 0);
+  } else if (epl <= 2) {
+    if (fpl <= 2) GKLT_TRACK_W(2, 2, 0); else GKLT_TRACK_W(2, 4, 0);
+  } else if (epl <= 4) {
+    if (fpl <= 4) GKLT_TRACK_W(4, 4, 0); else GKLT_TRACK_W(4, 8, 0);
+  } else if (epl <= 8) {
+    if (fpl <= 8) GKLT_TRACK_W(8, 8, 0); else GKLT_TRACK_W(8, 16, 0);
+  } else {
+    GKLT_TRACK_W(16, 16, 0);
+  }
+#undef GKLT_TRACK_W
+}
+
+}  // namespace
+
+// One launch for the lists of nstreams independent streams: stream i is tracked from its ring
+// slot slot1 to slot2 (texel planes in the device table tab, [nstreams][3][GKLT_MAX_LEVELS]) and
+// owns list entries [i * cap, i * cap + n[i]).  py0: any pyramid of the set (sizes).  mirror
+// (optional, host-visible) receives x | y | val with stride mirror_stride.
+int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, int nstreams,
+                         int slot1, int slot2, int cap, const int *n, const gklt_pyramid *py0,
+                         float *x, float *y, int *val, unsigned long long *stats, float *mirror,
+                         int mirror_stride) {
+  const gklt_params &P = ctx->prm;
+  if (nstreams < 1 || nstreams > GKLT_MAX_STREAMS) return GKLT_EINVAL;
+  if (py0->nlevels != P.nPyramidLevels || py0->ss != P.subsampling) {
+    set_error("pyramids were built for %d levels / subsampling %d, context has %d / %d",
+              py0->nlevels, py0->ss, P.nPyramidLevels, P.subsampling);
+    return GKLT_EINVAL;
+  }
+  const WaveGeom g = wave_geom(ctx, P.window_width, P.window_height);
+  if (!g.fits) {
+    set_error("window %dx%d is too large for the wave-per-feature tracker of multi-stream launches",
+              P.window_width, P.window_height);
+    return GKLT_EUNSUPPORTED;
+  }
+  TrackStreams M{};
+  M.tab = tab;
+  M.nstreams = nstreams;
+  M.slot1 = slot1;
+  M.slot2 = slot2;
+  M.cap = cap;
+  long total = 0;
+  for (int i = 0; i < nstreams; ++i) {
+    M.n[i] = n[i];
+    M.nmax = std::max(M.nmax, n[i]);
+    total += n[i];
+  }
+  if (total <= 0) return 0;
+  TrackArgs a;
+  fill_args(P, py0, M.nmax, false, mirror_stride, &a);
+  TrackFrames F{};
+  F.nframes = 1;
+  F.mirror[0] = mirror;
+  // slots of the launch: nstreams x 8 x ceil(nmax / 8); the default cap of 4096 wavefronts leaves
+  // room for the batched build the launch overlaps with
+  const long slots = (long)nstreams * 8 * ((M.nmax + 7) / 8);
+  const int nwaves = (int)std::min<long>(slots, ctx->track_waves > 0 ? ctx->track_waves : 4096);
+  ProfScope ps(ctx, s, GKLT_K_TRACK);
+  dispatch_w<true>(g, nwaves, s, a, F, M, x, y, val, nullptr, nullptr, nullptr, stats);
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
 // Tracks the list through nframes consecutive pairs (py[j], py[j+1]), j = 0..nframes-1; mirrors[j]
 // (optional, host-visible) receives the list after frame j.  One launch when the wave-per-feature
 // kernel applies, nframes launches otherwise.
@@ -723,42 +875,18 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
         return GKLT_EINVAL;
       }
   }
-  TrackArgs a{};
-  a.nlevels = P.nPyramidLevels;
-  a.ss = (float)P.subsampling;  // LK.hpp:978
-  a.inv_ss = (P.subsampling & (P.subsampling - 1)) == 0 ? 1.0f / (float)P.subsampling : 0.f;
-  a.ww = P.window_width;
-  a.wh = P.window_height;
-  a.step_factor = P.step_factor;
-  a.min_det = P.min_determinant;
-  a.min_disp = P.min_displacement;
-  a.max_residue = P.max_residue;
-  a.max_iter = P.max_iterations;
-  a.w0 = py[0]->lv[0].w;
-  a.h0 = py[0]->lv[0].h;
-  a.borderx = P.borderx;
-  a.bordery = P.bordery;
-  a.n = n;
-  a.do_epilogue = d_invk && d_norm && d_vec;
-  a.mirror_stride = mirror_stride;
+  TrackArgs a;
+  fill_args(P, py[0], n, d_invk && d_norm && d_vec, mirror_stride, &a);
   if (n <= 0) return 0;
 
-  const int NA = 8 * ((a.ww * a.wh + 8) / 8);
-  const int NF = (a.ww + 1) * (a.wh + 1);
-  // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
-  // 19.2 us at C2, 11x11 86 / 98 us at C3, 21x21 67 / 39 us at Cship); track_impl 2 / 3 force it.
-  const bool stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && a.ww * a.wh >= 200);
-  const int epl = (NA + 63) / 64, fpl = (NF + 63) / 64;
-  const size_t wlds = sizeof(float) * (size_t)(5 * NA + 40) + (stage ? sizeof(float4) * (size_t)NF : 0);
+  const WaveGeom g = wave_geom(ctx, a.ww, a.wh);
   const dim3 block(64);
 
-  if (ctx->track_impl != 1 && epl <= 16 && fpl <= 16 && wlds <= 48 * 1024) {  // feature per wave
+  if (ctx->track_impl != 1 && g.fits) {  // feature per wave
     if (a.do_epilogue && nframes != 1) {
       set_error("bearing vectors are produced by single-frame launches only");
       return GKLT_EINVAL;
     }
-    for (int l = 0; l < P.nPyramidLevels; ++l)
-      a.lv[l] = TrackLevel{nullptr, nullptr, py[0]->lv[l].w, py[0]->lv[l].h};
     // Default cap for multi-frame launches: 4 wavefronts per SIMD (256 CUs x 4 SIMDs).  A launch
     // that takes more of the chip's wave slots for the length of a whole batch starves the pyramid
     // build it overlaps with (C3, 16000 features, lookahead 16: cap 4096 -> 117 M, 8192 -> 112 M,
@@ -771,34 +899,7 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
       for (int l = 0; l < P.nPyramidLevels; ++l) F.tex[j][l] = py[j]->lv[l].tex;
     for (int j = 0; j < nframes; ++j) F.mirror[j] = mirrors ? mirrors[j] : nullptr;
     ProfScope ps(ctx, s, GKLT_K_TRACK);
-#define GKLT_TRACK_W(E, FP)                                                                    \
-  hipLaunchKernelGGL((k_track_w<E, FP>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,  \
-                     d_norm, d_vec, stats)
-    const int nec = NA / 8;
-    if (!stage) {
-      if (epl <= 1 && nec == 7) {  // 7x7
-        hipLaunchKernelGGL((k_track_w<1, 0, 7>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,
-                           d_norm, d_vec, stats);
-      } else if (epl <= 1) GKLT_TRACK_W(1, 0);
-      else if (epl <= 2 && nec == 16) {  // 11x11
-        hipLaunchKernelGGL((k_track_w<2, 0, 16>), dim3(nwaves), block, wlds, s, a, F, x, y, val, d_invk,
-                           d_norm, d_vec, stats);
-      } else if (epl <= 2) GKLT_TRACK_W(2, 0);
-      else if (epl <= 4) GKLT_TRACK_W(4, 0);
-      else if (epl <= 8) GKLT_TRACK_W(8, 0);
-      else GKLT_TRACK_W(16, 0);
-    } else if (epl <= 1) {
-      if (fpl <= 1) GKLT_TRACK_W(1, 1); else GKLT_TRACK_W(1, 2);
-    } else if (epl <= 2) {
-      if (fpl <= 2) GKLT_TRACK_W(2, 2); else GKLT_TRACK_W(2, 4);
-    } else if (epl <= 4) {
-      if (fpl <= 4) GKLT_TRACK_W(4, 4); else GKLT_TRACK_W(4, 8);
-    } else if (epl <= 8) {
-      if (fpl <= 8) GKLT_TRACK_W(8, 8); else GKLT_TRACK_W(8, 16);
-    } else {
-      GKLT_TRACK_W(16, 16);
-    }
-#undef GKLT_TRACK_W
+    dispatch_w<false>(g, nwaves, s, a, F, TrackStreams{}, x, y, val, d_invk, d_norm, d_vec, stats);
     GKLT_HIP(hipGetLastError());
     return 0;
   }

@@ -495,6 +495,79 @@ class Lookahead:
             self.h = C.c_void_p()
 
 
+class MultiStream:
+    """gklt_multistream: S independent streams on one GPU, one frame of each per step."""
+
+    def __init__(self, ctx, nstreams, W, H, capacity):
+        L = lib()
+        L.gklt_multistream_pyramid.restype = C.c_void_p
+        self.ctx, self.S, self.W, self.H, self.capacity = ctx, nstreams, W, H, capacity
+        self.h = C.c_void_p()
+        _check(L.gklt_multistream_create(ctx.h, nstreams, W, H, capacity, C.byref(self.h)))
+
+    def _imgs(self, imgs):
+        assert len(imgs) == self.S
+        parts = [Pipeline._img(f) for f in imgs]
+        strides = {q[2] for q in parts}
+        dev = {q[3] for q in parts}
+        assert len(strides) == 1 and len(dev) == 1
+        arr = (C.POINTER(C.c_uint8) * self.S)(*[q[1] for q in parts])
+        return parts, arr, strides.pop(), dev.pop()
+
+    def start(self, imgs0, imgs1):
+        k0, a0, s0, d0 = self._imgs(imgs0)
+        k1, a1, s1, d1 = self._imgs(imgs1)
+        assert s0 == s1 and d0 == d1
+        _check(lib().gklt_multistream_start(self.h, a0, a1, s0, d0))
+
+    def step(self, imgs_next=None, host_out=None):
+        """imgs_next: S numpy u8 images or S (device pointer, stride) pairs; host_out: address of
+        3 * S * capacity floats (pinned or not) or None."""
+        if imgs_next is None:
+            _check(lib().gklt_multistream_step(self.h, None, 0, 0, C.c_void_p(host_out)))
+            return
+        keep, arr, stride, dev = self._imgs(imgs_next)
+        _check(lib().gklt_multistream_step(self.h, arr, stride, dev, C.c_void_p(host_out)))
+        if not dev:
+            self.sync()  # pageable host frames must stay alive until staged
+
+    def upload_features(self, stream, x, y, val):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y, np.float32)
+        val = np.ascontiguousarray(val, np.int32)
+        _check(lib().gklt_multistream_upload_features(self.h, stream, len(x), _fp(x), _fp(y), _ip(val)))
+        self.sync()  # the arrays may be temporaries
+
+    def download(self, stream):
+        n = lib().gklt_multistream_size(self.h, stream)
+        _check(min(n, 0))
+        x, y, v = np.empty(n, np.float32), np.empty(n, np.float32), np.empty(n, np.int32)
+        _check(lib().gklt_multistream_download(self.h, stream, _fp(x), _fp(y), _ip(v)))
+        return x, y, v
+
+    def stats(self, reset=False):
+        t, i = C.c_uint64(), C.c_uint64()
+        _check(lib().gklt_multistream_stats(self.h, C.byref(t), C.byref(i), int(reset)))
+        return t.value, i.value
+
+    def sync(self):
+        _check(lib().gklt_multistream_sync(self.h))
+
+    def wait_tracked(self):
+        _check(lib().gklt_multistream_wait_tracked(self.h))
+
+    def pyramid(self, stream, which):
+        py = Pyramid.__new__(Pyramid)
+        py.ctx, py.W, py.H = self.ctx, self.W, self.H
+        py.h = C.c_void_p(lib().gklt_multistream_pyramid(self.h, stream, which))
+        return py
+
+    def close(self):
+        if self.h:
+            lib().gklt_multistream_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def KLTTrackFeatures(ctx, pyr1, pyr2, x, y, val, invK=None):
     """LK.hpp:972 -- returns updated copies (x, y, val[, norm, vec])."""
     x = np.array(x, np.float32)

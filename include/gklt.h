@@ -24,6 +24,7 @@ extern "C" {
 #define GKLT_MAX_KERNEL_WIDTH 71 /* KLT.h:107 MAX_KERNEL_WIDTH */
 #define GKLT_MAX_LEVELS 12
 #define GKLT_MAX_LOOKAHEAD 16 /* frames per batched build / multi-frame tracker launch */
+#define GKLT_MAX_STREAMS 64   /* video streams of one gklt_multistream */
 
 /* KLT.h:69-74 */
 #define GKLT_TRACKED 0
@@ -265,6 +266,42 @@ int gklt_lookahead_sync(gklt_lookahead *p);
 gklt_flist *gklt_lookahead_flist(gklt_lookahead *p);
 /* Index of the last frame the list has been tracked to (enqueued, not necessarily finished). */
 long gklt_lookahead_frames_tracked(gklt_lookahead *p);
+
+/* ---- several independent streams on one GPU, stepped together (BASELINE config 4) ---- */
+
+/* nstreams (<= GKLT_MAX_STREAMS) independent video streams of the same size, each with the state
+ * of a gklt_pipeline (a 3-deep pyramid ring as PyramidBuffer, System.h:30-56, and a device feature
+ * list), advanced one frame per call as System::Track does (System.cpp:501-518): the pyramids of
+ * the streams' NEXT frames are built while every list is tracked previous -> current.  The work of
+ * a step is batched over the streams instead of over time -- one launch per pyramid level for up to
+ * GKLT_MAX_LOOKAHEAD streams, one tracker launch for all lists -- so live streams, which cannot be
+ * looked ahead, get the launch structure of gklt_lookahead without its one-batch delay.  Every
+ * stream's lists are those of its own gklt_pipeline, bit for bit.  Streams are independent (the
+ * multi-GPU partition of SURVEY 8e is whole streams -> GPUs; this object holds one GPU's share).
+ *   imgs / imgs_next   nstreams frame pointers (all host or all device), one row stride
+ *   host_out           NULL, or x[S*capacity] | y[S*capacity] | val[S*capacity] with stream s at
+ *                      offset s*capacity of each part; pinning rule as gklt_pipeline_step */
+typedef struct gklt_multistream gklt_multistream;
+int gklt_multistream_create(gklt_ctx *ctx, int nstreams, int width, int height, int capacity,
+                            gklt_multistream **out);
+int gklt_multistream_destroy(gklt_multistream *m);
+int gklt_multistream_start(gklt_multistream *m, const uint8_t *const *imgs0,
+                           const uint8_t *const *imgs1, int stride, int img_on_device);
+/* imgs_next may be NULL for the last frame (track only). */
+int gklt_multistream_step(gklt_multistream *m, const uint8_t *const *imgs_next, int stride,
+                          int img_on_device, void *host_out);
+/* Replaces the list of one stream (ordered with the steps). */
+int gklt_multistream_upload_features(gklt_multistream *m, int stream, int n, const float *x,
+                                     const float *y, const int *val);
+/* Blocking download of one stream's list (n entries each). */
+int gklt_multistream_download(gklt_multistream *m, int stream, float *x, float *y, int *val);
+int gklt_multistream_size(const gklt_multistream *m, int stream);
+int gklt_multistream_sync(gklt_multistream *m);
+int gklt_multistream_wait_tracked(gklt_multistream *m);
+/* Counters over all streams since the last reset, as gklt_flist_stats. */
+int gklt_multistream_stats(gklt_multistream *m, uint64_t *tracked, uint64_t *iterations, int reset);
+/* Pyramid of one stream (which = 0 previous, 1 current) for downloads; sync first. */
+gklt_pyramid *gklt_multistream_pyramid(gklt_multistream *m, int stream, int which);
 
 /* ---- memory helpers for callers that have no HIP of their own (no reference counterpart) ---- */
 

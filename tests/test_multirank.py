@@ -17,7 +17,8 @@ WORKER = textwrap.dedent("""
     # each rank "measured" a different time and count
     dt, tracked, iters = bench.reduce_over_ranks(dist, 1.0 + r, 1000 * (r + 1), 10 * (r + 1))
     seeds = bench.rank_seed(r)
-    out = dict(rank=r, dt=dt, tracked=tracked, iters=iters, seed=seeds)
+    out = dict(rank=r, dt=dt, tracked=tracked, iters=iters, seed=seeds,
+               streams=bench.shard_streams(7, dist.get_world_size(), r))
     print("RESULT " + json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -42,3 +43,5 @@ def test_two_rank_reduction_and_sharding(tmp_path):
         assert d["tracked"] == 3000.0    # summed over ranks
         assert d["iters"] == 30.0
     assert res[0]["seed"] != res[1]["seed"]   # independent streams per rank
+    # config 4: stream s -> rank s mod world; every stream on exactly one rank
+    assert res[0]["streams"] == [0, 2, 4, 6] and res[1]["streams"] == [1, 3, 5]
