@@ -10,8 +10,9 @@
 // step of S streams costs 4*ceil(S/16) + 1 launches and two event waits, and the tracker's
 // wavefronts average over S*N features.
 //
-// Streams: P builds, T tracks.  step(t) enqueues   P: wait(T of step t-1); build frames t+1
-//                                                  T: wait(P of step t-1); track t-1 -> t
+// Streams: P builds, T tracks (the context's s_pyr and s_trk).
+//   step(t) enqueues   P: wait(T of step t-1); build frames t+1
+//                      T: wait(P of step t-1); track t-1 -> t
 // so build(t+1) overlaps track(t).  build(t+1) overwrites ring slot (t+1)%3 = (t-2)%3, last read
 // by the tracker launch of step t-1.
 #include <vector>
@@ -66,8 +67,6 @@ extern "C" int gklt_multistream_destroy(gklt_multistream *m) {
   if (m->d_tab) (void)hipFree(m->d_tab);
   if (m->e_built) (void)hipEventDestroy(m->e_built);
   if (m->e_tracked) (void)hipEventDestroy(m->e_tracked);
-  if (m->sp) (void)hipStreamDestroy(m->sp);
-  if (m->st) (void)hipStreamDestroy(m->st);
   delete m;
   return 0;
 }
@@ -104,11 +103,15 @@ extern "C" int gklt_multistream_create(gklt_ctx *ctx, int nstreams, int width, i
       rc = GKLT_EHIP;
     }
   }
-  if (!rc && (hipStreamCreateWithFlags(&m->sp, hipStreamNonBlocking) != hipSuccess ||
-              hipStreamCreateWithFlags(&m->st, hipStreamNonBlocking) != hipSuccess ||
-              hipEventCreateWithFlags(&m->e_built, hipEventDisableTiming) != hipSuccess ||
+  // The context's two streams, not streams of its own: a process has GPU_MAX_HW_QUEUES (4)
+  // hardware queues, further HIP streams share them, and two streams that land on the same queue
+  // run their kernels one after the other (seen with rocprofv3: builds and tracker of a step on
+  // one queue, no overlap, when the object created a fifth and sixth stream).
+  m->sp = ctx->s_pyr;
+  m->st = ctx->s_trk;
+  if (!rc && (hipEventCreateWithFlags(&m->e_built, hipEventDisableTiming) != hipSuccess ||
               hipEventCreateWithFlags(&m->e_tracked, hipEventDisableTiming) != hipSuccess)) {
-    set_error("multi-stream streams/events could not be created");
+    set_error("multi-stream events could not be created");
     rc = GKLT_EHIP;
   }
   if (rc) {

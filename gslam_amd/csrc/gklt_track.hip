@@ -500,16 +500,35 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   // q % 8 is still the XCD).
   const int per_xcd = ((MS ? M.nmax : a.n) + 7) >> 3;
   const int qs = 8 * per_xcd;
-  for (int q = blockIdx.x; q < (MS ? M.nstreams * qs : qs); q += gridDim.x) {
+  const int qend = MS ? M.nstreams * qs : qs;
+  // slot -> list entry (-1: none) and its (x, y, val).  The entry of the wavefront's NEXT slot is
+  // loaded before the current feature is tracked, so that the loads' latency is not paid between
+  // features (a launch visits every entry once, so nothing else writes it meanwhile).
+  auto fetch = [&](int q, int &f, float &x, float &y, int &v) {
+    f = -1;
+    if (q >= qend) return;
+    const int sidx = MS ? q / qs : 0;
+    const int ql = q - sidx * qs;
+    const int fl = (ql & 7) * per_xcd + (ql >> 3);
+    if (fl >= (MS ? M.n[sidx] : a.n)) return;
+    f = MS ? sidx * M.cap + fl : fl;
+    v = fval[f];
+    x = fx[f];
+    y = fy[f];
+  };
+  unsigned w_tracked = 0, w_iters = 0;  // this wavefront's counters (< 2^32 per launch)
+  int f_next, v_next = 0;
+  float x_next = 0.f, y_next = 0.f;
+  fetch(blockIdx.x, f_next, x_next, y_next, v_next);
+  for (int q = blockIdx.x; q < qend; q += gridDim.x) {
+  const int f = f_next;
+  const int val0 = v_next;
+  float px = x_next, py = y_next;  // the feature's position in the first frame of the launch
+  fetch(q + gridDim.x, f_next, x_next, y_next, v_next);
+  if (f < 0) continue;
   const int sidx = MS ? q / qs : 0;
-  const int ql = q - sidx * qs;
-  const int fl = (ql & 7) * per_xcd + (ql >> 3);
-  if (fl >= (MS ? M.n[sidx] : a.n)) continue;
-  const int f = MS ? sidx * M.cap + fl : fl;
   const Texel *const *const tab1 = MS ? M.tab + (size_t)(sidx * 3 + M.slot1) * GKLT_MAX_LEVELS : nullptr;
   const Texel *const *const tab2 = MS ? M.tab + (size_t)(sidx * 3 + M.slot2) * GKLT_MAX_LEVELS : nullptr;
-  const int val0 = fval[f];
-  float px = fx[f], py = fy[f];  // the feature's position in the first frame of the launch
   int vcur = val0;
   int iters_total = 0, ntracked = 0;
   for (int fr = 0; fr < F.nframes; ++fr) {
@@ -699,17 +718,25 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   __syncthreads();  // LDS is reused by the next frame
   }  // frames
 
-  if (val0 >= 0 && lane == 0) {
-    fx[f] = px;
-    fy[f] = py;
-    fval[f] = vcur;
-    if (stats) {  // sharded: thousands of adds to one word would serialise at the memory side
-      unsigned long long *sh = stats + 2 * (f & (kStatShards - 1));
-      if (ntracked) atomicAdd(&sh[0], (unsigned long long)ntracked);
-      atomicAdd(&sh[1], (unsigned long long)iters_total);
+  if (val0 >= 0) {
+    if (lane == 0) {
+      fx[f] = px;
+      fy[f] = py;
+      fval[f] = vcur;
     }
+    w_tracked += ntracked;
+    w_iters += iters_total;
   }
   }  // features of this wavefront
+  // Counters: one pair of atomics per wavefront, after its last feature (on gfx9 stores and atomics
+  // count in vmcnt like loads, so an atomic per feature would make the next feature's first
+  // gather wait for its round trip); sharded, because thousands of adds to one word would
+  // serialise at the memory side.
+  if (stats && lane == 0 && (w_tracked | w_iters)) {
+    unsigned long long *sh = stats + 2 * (blockIdx.x & (kStatShards - 1));
+    if (w_tracked) atomicAdd(&sh[0], (unsigned long long)w_tracked);
+    atomicAdd(&sh[1], (unsigned long long)w_iters);
+  }
 }
 
 }  // namespace

@@ -504,6 +504,7 @@ class MultiStream:
         self.ctx, self.S, self.W, self.H, self.capacity = ctx, nstreams, W, H, capacity
         self.h = C.c_void_p()
         _check(L.gklt_multistream_create(ctx.h, nstreams, W, H, capacity, C.byref(self.h)))
+        self._seed = {}
 
     def _imgs(self, imgs):
         assert len(imgs) == self.S
@@ -535,8 +536,8 @@ class MultiStream:
         x = np.ascontiguousarray(x, np.float32)
         y = np.ascontiguousarray(y, np.float32)
         val = np.ascontiguousarray(val, np.int32)
+        self._seed[stream] = (x, y, val)  # the copies are asynchronous: keep the arrays alive
         _check(lib().gklt_multistream_upload_features(self.h, stream, len(x), _fp(x), _fp(y), _ip(val)))
-        self.sync()  # the arrays may be temporaries
 
     def download(self, stream):
         n = lib().gklt_multistream_size(self.h, stream)

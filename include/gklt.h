@@ -278,6 +278,9 @@ long gklt_lookahead_frames_tracked(gklt_lookahead *p);
  * looked ahead, get the launch structure of gklt_lookahead without its one-batch delay.  Every
  * stream's lists are those of its own gklt_pipeline, bit for bit.  Streams are independent (the
  * multi-GPU partition of SURVEY 8e is whole streams -> GPUs; this object holds one GPU's share).
+ * The work is enqueued on the context's own two HIP streams (a process has few hardware queues;
+ * objects that bring streams of their own end up sharing them), so one context = one
+ * gklt_multistream at a time.
  *   imgs / imgs_next   nstreams frame pointers (all host or all device), one row stride
  *   host_out           NULL, or x[S*capacity] | y[S*capacity] | val[S*capacity] with stream s at
  *                      offset s*capacity of each part; pinning rule as gklt_pipeline_step */

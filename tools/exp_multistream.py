@@ -12,6 +12,7 @@ cfgname = os.environ.get("GKLT_CONFIG", "C2")
 cfg = dict(synth.CONFIGS[cfgname]); H, W, n = cfg["H"], cfg["W"], cfg["n"]
 gp = klt.make_params(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
 ctx = klt.Context(0, gp)
+ctx.set_track_waves(int(os.environ.get("GKLT_TRACK_WAVES", "0")))
 NF = 64
 frames = synth.make_stream(H, W, NF, seed=synth.BASE_SEED)
 dptr = [ctx.device_upload(f) for f in frames]
