@@ -10,7 +10,7 @@
 // Results are those of frame-at-a-time calls, bit for bit.  Per batch the host enqueues
 // nlevels + 1 launches and two event waits, independent of the batch size.
 //
-// Streams: P builds, T tracks.  submit(k) enqueues  P: wait(T done k-1); build batch k
+// Streams (the context's s_pyr / s_trk): P builds, T tracks.  submit(k) enqueues  P: wait(T done k-1); build batch k
 //                                                   T: wait(P done k-1); track batch k-1
 // so build(k) overlaps track(k-1).  The ring holds 2*max_batch+1 pyramids: batch k overwrites the
 // slots of frames that the tracker launch of submit(k-1) was the last to read.
@@ -57,11 +57,14 @@ extern "C" int gklt_lookahead_create(gklt_ctx *ctx, int width, int height, int c
   for (size_t i = 0; i < p->ring.size() && !rc; ++i)
     rc = gklt_pyramid_create(ctx, width, height, &p->ring[i]);
   if (!rc) rc = gklt_flist_create(ctx, capacity, &p->fl);
-  if (!rc && (hipStreamCreateWithFlags(&p->sp, hipStreamNonBlocking) != hipSuccess ||
-              hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking) != hipSuccess ||
-              hipEventCreateWithFlags(&p->e_built, hipEventDisableTiming) != hipSuccess ||
+  // The context's two streams: a process has GPU_MAX_HW_QUEUES (4) hardware queues, HIP streams
+  // beyond that share them, and two streams on one queue run their kernels one after the other
+  // (seen with rocprofv3 for gklt_multistream when it brought two more streams of its own).
+  p->sp = ctx->s_pyr;
+  p->st = ctx->s_trk;
+  if (!rc && (hipEventCreateWithFlags(&p->e_built, hipEventDisableTiming) != hipSuccess ||
               hipEventCreateWithFlags(&p->e_tracked, hipEventDisableTiming) != hipSuccess)) {
-    set_error("lookahead streams/events could not be created");
+    set_error("lookahead events could not be created");
     rc = GKLT_EHIP;
   }
   if (rc) {
@@ -91,8 +94,6 @@ extern "C" int gklt_lookahead_destroy(gklt_lookahead *p) {
     if (b) (void)hipFree(b);
   if (p->e_built) (void)hipEventDestroy(p->e_built);
   if (p->e_tracked) (void)hipEventDestroy(p->e_tracked);
-  if (p->sp) (void)hipStreamDestroy(p->sp);
-  if (p->st) (void)hipStreamDestroy(p->st);
   delete p;
   return 0;
 }

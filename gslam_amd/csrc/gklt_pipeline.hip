@@ -71,9 +71,11 @@ extern "C" int gklt_pipeline_create(gklt_ctx *ctx, int width, int height, int ca
   for (int i = 0; i < 3 && !rc; ++i) rc = gklt_pyramid_create(ctx, width, height, &p->ring[i]);
   if (!rc) rc = gklt_flist_create(ctx, capacity, &p->fl);
   for (int i = 0; i < 2 && !rc; ++i) {
+    // the context's two streams (see gklt_lookahead_create: streams of its own could end up on
+    // one hardware queue)
+    p->st[i] = i ? ctx->s_trk : ctx->s_pyr;
     if (hipMalloc(&p->d_stage[i], (size_t)width * height) != hipSuccess) rc = GKLT_ENOMEM;
-    else if (hipStreamCreateWithFlags(&p->st[i], hipStreamNonBlocking) != hipSuccess ||
-             hipEventCreateWithFlags(&p->e_trk[i], hipEventDisableTiming) != hipSuccess)
+    else if (hipEventCreateWithFlags(&p->e_trk[i], hipEventDisableTiming) != hipSuccess)
       rc = GKLT_EHIP;
   }
   if (rc) {
@@ -117,7 +119,6 @@ extern "C" int gklt_pipeline_destroy(gklt_pipeline *p) {
   for (int i = 0; i < 2; ++i) {
     if (p->d_stage[i]) (void)hipFree(p->d_stage[i]);
     if (p->e_trk[i]) (void)hipEventDestroy(p->e_trk[i]);
-    if (p->st[i]) (void)hipStreamDestroy(p->st[i]);
   }
   delete p;
   return 0;
