@@ -33,13 +33,17 @@ struct Taps {
   float k[kMaxRadius + 1];
 };
 
-// One pixel of a pyramid level as the tracker reads it: (I, gx, gy, 0).
-using Texel = float4;
+// One pixel of a pyramid level as the tracker reads it: (I, gx, gy), 12 bytes, so that one
+// bilinear tap is one global_load_dwordx3 that brings all three planes.  (A 16-byte texel with a
+// zero pad costs a quarter more HBM write traffic in the level kernels and L2 space in the tracker.)
+struct Texel {
+  float x, y, z;
+};
 
 struct Level {
   int w = 0, h = 0;
   float *img = nullptr;  // planar I, w*h
-  Texel *tex = nullptr;  // interleaved (I, gx, gy, 0), w*h
+  Texel *tex = nullptr;  // interleaved (I, gx, gy), w*h
 };
 
 }  // namespace gklt

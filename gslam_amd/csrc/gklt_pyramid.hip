@@ -17,8 +17,8 @@
 // instantiation, which keeps the taps in LDS.
 //
 // HBM layout written here: per level a planar fp32 image `img` (input of the
-// next level, downloads) and an interleaved texel array (I, gx, gy, 0) that the tracker gathers
-// with one 16-byte load per bilinear tap.
+// next level, downloads) and an interleaved texel array (I, gx, gy) that the tracker gathers
+// with one 12-byte load per bilinear tap.
 #include "gklt_internal.h"
 
 namespace gklt {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(NT) void k_grad(GradBatch batch, Taps g, Taps d) {
     const float gy = corr<RD, -1>(rowg + (ty + r) * TW + lane, TW, td);
     if (x < w && y < h) {
       if (J.tex) {
-        J.tex[(size_t)y * w + x] = make_float4(in[(ty + r) * inW + lane + r], gx, gy, 0.0f);
+        J.tex[(size_t)y * w + x] = Texel{in[(ty + r) * inW + lane + r], gx, gy};
       } else {
         J.gx[(size_t)y * w + x] = gx;
         J.gy[(size_t)y * w + x] = gy;
@@ -410,8 +410,7 @@ __global__ __launch_bounds__(NT) void k_grad_fast(GradBatch batch, Taps g, Taps 
     const float gy = corr_win<R, -1>(vg, R + j, d);
     if (x < w && y < h) {
       if (J.tex) {
-        J.tex[(size_t)y * w + x] =
-            make_float4(in[(4 * wave + j + R) * G::IWP + G::HP + lane], gx, gy, 0.0f);
+        J.tex[(size_t)y * w + x] = Texel{in[(4 * wave + j + R) * G::IWP + G::HP + lane], gx, gy};
       } else {
         J.gx[(size_t)y * w + x] = gx;
         J.gy[(size_t)y * w + x] = gy;
@@ -433,7 +432,7 @@ constexpr size_t fast_grad_lds() {
 // One launch per pyramid level does everything that level needs:
 //   level 0 : u8 tile -> smooth(sigma0) -> I (in LDS only)        (pyramid.cpp:59-61)
 //   level l : planar I_l tile -> I (in LDS)
-//   then    : gradients of I -> texels (I, gx, gy, 0)             (pyramid.cpp:72-83)
+//   then    : gradients of I -> texels (I, gx, gy)                (pyramid.cpp:72-83)
 //             smooth(sigma_pyr) of I -> 2x2 mean -> planar I_{l+1} (pyramid.cpp:62-66)
 // so a level's image is read from HBM once, level 0's fp32 plane is never written, and a build is
 // nlevels launches.  I is produced with a halo of HI = max(RP, RG) pixels around the tile; at
@@ -625,8 +624,10 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
       if (x < w && y < h) {
         // streaming store: the texels are next read by a tracker launch at least one build
         // later, and must not evict the window footprints a concurrent tracker gathers from L2
-        const v4f t = {ic, gx, gy, 0.0f};
-        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(tex + (size_t)y * w + x));
+        Texel *const t = tex + (size_t)y * w + x;  // the three stores merge into one dwordx3
+        __builtin_nontemporal_store(ic, &t->x);
+        __builtin_nontemporal_store(gx, &t->y);
+        __builtin_nontemporal_store(gy, &t->z);
         if (img_out) img_out[(size_t)y * w + x] = ic;
       }
     }
@@ -707,7 +708,6 @@ __global__ void k_tex_insert(Texel *__restrict__ tex, int n, int comp,
   Texel t = tex[i];
   const float v = src[i];
   if (comp == 0) t.x = v; else if (comp == 1) t.y = v; else t.z = v;
-  t.w = 0.0f;
   tex[i] = t;
 }
 

@@ -11,7 +11,7 @@
 //
 // All pyramid levels and all Newton iterations of a feature run inside one launch.  The
 // template patch (I, gx, gy of frame 1) lives in registers for the instantiated window sizes
-// and in LDS for the generic kernel.  Each bilinear tap is one 16-byte load of an (I,gx,gy,0)
+// and in LDS for the generic kernel.  Each bilinear tap is one 12-byte load of an (I,gx,gy)
 // texel (layout written by gklt_pyramid.hip).
 #include <algorithm>
 
