@@ -44,8 +44,8 @@ def _pmc_bytes(fetch_kib, write_kib, frames):
     return (2.0 * fetch_kib + write_kib) * 1024.0 / frames
 
 
-PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(167600.0, 1315.0, 16),
-               ("C2", "level0"): _pmc_bytes(76570.0, 550800.0, 16)}
+PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(121500.0, 1294.0, 16),
+               ("C2", "level0"): _pmc_bytes(76570.0, 421200.0, 16)}
 
 
 def parse():
@@ -256,11 +256,11 @@ def shard_streams(total, world, rank):
 
 class MultiStreamSet:
     """This rank's share of the config-4 streams behind one gklt_multistream.  To bound host-side
-    generation time the rank renders at most 4 distinct synthetic sequences; stream s plays
-    sequence s mod 4 from phase 5*s (frames are read-only in HBM, so streams share the copies).
+    generation time the rank renders at most 2 distinct synthetic sequences; stream s plays
+    sequence s mod 2 from phase 5*s (frames are read-only in HBM, so streams share the copies).
     Every stream has its own pyramid ring and feature list and does the full per-frame work."""
 
-    NSEQ = 4
+    NSEQ = 2
 
     def __init__(self, ctx, cfg, ids, nframes, gp):
         H, W, n = cfg["H"], cfg["W"], cfg["n"]
@@ -320,7 +320,7 @@ def main_multistream(a, ctx, cfg, gp, dist, rank, world):
     ids = shard_streams(a.streams, world, rank)
     if not ids:
         raise SystemExit("--streams must be at least the number of GPUs")
-    st = MultiStreamSet(ctx, cfg, ids, min(a.frames, 16), gp)
+    st = MultiStreamSet(ctx, cfg, ids, a.frames, gp)
     st.start()
     steps, warm = a.steps, a.warmup
 
