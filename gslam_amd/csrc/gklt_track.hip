@@ -115,6 +115,13 @@ __device__ __forceinline__ float sample_i(const Texel *__restrict__ base, int nc
   return (p00 * b.w0 + p01 * b.w1) + (p10 * b.w2 + p11 * b.w3);
 }
 
+// The value of lane l+1 (lane 63: unspecified) through a DPP wave shift: a VALU move, no trip
+// through the LDS crossbar.
+__device__ __forceinline__ float from_next_lane(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false));
+}
+
 // lanes 0..7 of the slice added left to right; every lane of the slice gets the total.
 __device__ __forceinline__ float slice_sum(float v) {
   float t = __shfl(v, 0, SL);
@@ -388,7 +395,16 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // NEC = elements per AVX-lane chain when known at compile time (7x7: 7, 11x11: 16, 21x21: 56;
 // 0 = run time): the chain sums then unroll into NEC reads followed by NEC ordered adds.
 // MS: multi-stream launch (TrackStreams M names the pyramids and list segments, F.nframes == 1).
-template <int EPL, int FPL, int NEC = 0, bool MS = false>
+// FRM: footprint-in-registers sampling for windows whose bilinear footprint (w+1)(h+1) fits one
+// wavefront (7x7: exactly 64 texels).  Lane l holds footprint texel (l / (w+1), l % (w+1)), loaded
+// with ONE global_load_dwordx3 per patch instead of four gathers per element; the right and lower
+// neighbours come from lanes l+1 and l+(w+1).  The interpolation is evaluated as
+//   (t00*w0 + t01*w1) + B(l + (w+1)),   B(l) = t(l)*w2 + t(l+1)*w3
+// which is the reference's expression, operation for operation (B(l+(w+1)) is t10*w2 + t11*w3).
+// The texture path then sees a quarter of the lane-addresses and about a sixth of the cache
+// accesses.  Window element (r, c) sits in lane r*(w+1)+c and keeps its row-major index r*w+c
+// for the ordered reductions.
+template <int EPL, int FPL, int NEC = 0, bool MS = false, bool FRM = false>
 __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, TrackStreams M,
                                                 float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
@@ -410,16 +426,56 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   const int FW = ww + 1, NF = FW * (wh + 1);
 
   // element -> texel offset inside the window (tail elements clamp to the last pixel, value 0)
-  int eoff_x[EPL], eoff_y[EPL];
+  // and -> index of its products in prod[] (-1: none)
+  int eoff_x[EPL], eoff_y[EPL], pidx[EPL];
   bool evalid[EPL];
+  if constexpr (FRM) {
+    static_assert(EPL == 1 && FPL == 0, "one footprint texel per lane");
+    const int jc = min(lane, NF - 1);
+    eoff_y[0] = jc / FW;
+    eoff_x[0] = jc - eoff_y[0] * FW;
+    evalid[0] = lane < NF && eoff_y[0] < wh && eoff_x[0] < ww;
+    // the zero tail npix..NA-1 of the padded patch is written by the first lanes that hold no
+    // window element
+    const unsigned long long spare = __ballot(!evalid[0]);
+    const int rank = __popcll(spare & ((1ull << lane) - 1ull));
+    pidx[0] = evalid[0] ? eoff_y[0] * ww + eoff_x[0] : (rank < NA - npix ? npix + rank : -1);
+  } else {
 #pragma unroll
-  for (int e = 0; e < EPL; ++e) {
-    const int i = e * 64 + lane;
-    const int ic = min(i, npix - 1);
-    eoff_y[e] = ic / ww;
-    eoff_x[e] = ic - eoff_y[e] * ww;
-    evalid[e] = i < npix;
+    for (int e = 0; e < EPL; ++e) {
+      const int i = e * 64 + lane;
+      const int ic = min(i, npix - 1);
+      eoff_y[e] = ic / ww;
+      eoff_x[e] = ic - eoff_y[e] * ww;
+      evalid[e] = i < npix;
+      pidx[e] = i < NA ? i : -1;
+    }
   }
+  // one patch element for all three planes / for the image plane only
+  auto gather3 = [&](const Texel *__restrict__ p, int nc, const Bilin &b) {
+    if constexpr (FRM) {
+      const Texel t = *p;
+      const float nx = from_next_lane(t.x), ny = from_next_lane(t.y), nz = from_next_lane(t.z);
+      const float bx = t.x * b.w2 + nx * b.w3, by = t.y * b.w2 + ny * b.w3, bz = t.z * b.w2 + nz * b.w3;
+      float3 o;
+      o.x = (t.x * b.w0 + nx * b.w1) + __shfl_down(bx, FW);
+      o.y = (t.y * b.w0 + ny * b.w1) + __shfl_down(by, FW);
+      o.z = (t.z * b.w0 + nz * b.w1) + __shfl_down(bz, FW);
+      return o;
+    } else {
+      return sample(p, nc, b);
+    }
+  };
+  auto gather1 = [&](const Texel *__restrict__ p, int nc, const Bilin &b) {
+    if constexpr (FRM) {
+      const float t = p->x;
+      const float n = from_next_lane(t);
+      const float bl = t * b.w2 + n * b.w3;
+      return (t * b.w0 + n * b.w1) + __shfl_down(bl, FW);
+    } else {
+      return sample_i(p, nc, b);
+    }
+  };
   // footprint texel j = e*64 + lane -> offset inside the footprint (clamped past the end)
   int foff_x[FP], foff_y[FP];
   if (STAGE) {
@@ -589,9 +645,9 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
       } else {
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) T1[e] = sample(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
+        for (int e = 0; e < EPL; ++e) T1[e] = gather3(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+        for (int e = 0; e < EPL; ++e) S2[e] = gather3(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
       }
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
@@ -601,12 +657,12 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       for (;;) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const int i = e * 64 + lane;
+          const int i = pidx[e];
           const float3 s = evalid[e] ? S2[e] : make_float3(0.f, 0.f, 0.f);
           const float diff = T1[e].x - s.x;  // computeImageDiff :110-116
           const float gx = T1[e].y + s.y;    // computeImageSum  :118-125
           const float gy = T1[e].z + s.z;
-          if (i < NA) {
+          if (i >= 0) {
             prod[0 * NA + i] = gx * gx;      // compute2X2GradientMatrix :127-146
             prod[1 * NA + i] = gy * gy;
             prod[2 * NA + i] = gx * gy;
@@ -642,7 +698,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
         } else {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) S2[e] = sample(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+          for (int e = 0; e < EPL; ++e) S2[e] = gather3(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
         }
       }
 
@@ -664,13 +720,13 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           for (int e = 0; e < EPL; ++e) sI[e] = fp_sample(e, b2).x;
         } else {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) sI[e] = sample_i(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
+          for (int e = 0; e < EPL; ++e) sI[e] = gather1(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
         }
         __syncthreads();  // chain sums of the last iteration have been read
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-          const int i = e * 64 + lane;
-          if (i < NA) prod[i] = evalid[e] ? fabsf(T1[e].x - sI[e]) : 0.f;  // :193-208
+          const int i = pidx[e];
+          if (i >= 0) prod[i] = evalid[e] ? fabsf(T1[e].x - sI[e]) : 0.f;  // :193-208
         }
         float tot[5];
         reduce(1, tot);
@@ -778,7 +834,7 @@ void fill_args(const gklt_params &P, const gklt_pyramid *py0, int n, bool epilog
 
 struct WaveGeom {
   int NA, NF, epl, fpl;
-  bool stage, fits;
+  bool stage, fits, frm;
   size_t lds;
 };
 
@@ -793,6 +849,9 @@ WaveGeom wave_geom(const gklt_ctx *ctx, int ww, int wh) {
   g.fpl = (g.NF + 63) / 64;
   g.lds = sizeof(float) * (size_t)(5 * g.NA + 40) + (g.stage ? sizeof(float4) * (size_t)g.NF : 0);
   g.fits = g.epl <= 16 && g.fpl <= 16 && g.lds <= 48 * 1024;
+  // footprint-in-registers sampling: the whole (w+1)(h+1) footprint in one wavefront
+  // (track_impl 2 keeps the four gathers per element for A/B runs)
+  g.frm = !g.stage && g.NF <= 64 && ctx->track_impl != 2;
   return g;
 }
 
@@ -807,9 +866,14 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
 #define GKLT_TRACK_W(E, FP, NE)                                                                 \
   hipLaunchKernelGGL((k_track_w<E, FP, NE, MS>), dim3(nwaves), block, wlds, s, a, F, M, x, y, val, \
                      d_invk, d_norm, d_vec, stats)
+#define GKLT_TRACK_FRM(NE)                                                                      \
+  hipLaunchKernelGGL((k_track_w<1, 0, NE, MS, true>), dim3(nwaves), block, wlds, s, a, F, M, x, y, \
+                     val, d_invk, d_norm, d_vec, stats)
   const int nec = g.NA / 8;
   if (!g.stage) {
-    if (epl <= 1 && nec == 7) GKLT_TRACK_W(1, 0, 7);  // 7x7
+    if (g.frm && nec == 7) GKLT_TRACK_FRM(7);  // 7x7, footprint in registers
+    else if (g.frm) GKLT_TRACK_FRM(0);
+    else if (epl <= 1 && nec == 7) GKLT_TRACK_W(1, 0, 7);  // 7x7
     else if (epl <= 1) GKLT_TRACK_W(1, 0, 0);
     else if (epl <= 2 && nec == 16) GKLT_TRACK_W(2, 0, 16);  // 11x11
     else if (epl <= 2) GKLT_TRACK_W(2, 0, 0);
@@ -828,6 +892,7 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
     GKLT_TRACK_W(16, 16, 0);
   }
 #undef GKLT_TRACK_W
+#undef GKLT_TRACK_FRM
 }
 
 }  // namespace
