@@ -723,7 +723,8 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
 }
 
 // 0 = one feature per wavefront, LDS footprint staging chosen by window size (default);
-// 1 = one feature per 8-lane slice; 2 / 3 = one feature per wavefront without / with staging
+// 1 = one feature per 8-lane slice; 2 / 3 = one feature per wavefront with four gathers per
+// element / with LDS staging (0 picks footprint-in-registers, gathers or staging by window size)
 extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->track_impl = impl;
