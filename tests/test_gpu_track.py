@@ -50,6 +50,7 @@ def _assert_same(got, ref):
     (21, 2, 200, 320, 300),     # as-shipped window: generic LDS path
     (5, 3, 135, 240, 333),      # generic path, n not a multiple of 8
     (9, 2, 135, 240, 64),
+    (3, 2, 135, 240, 100),      # smallest window: footprint-in-registers sampling, 7 tail entries
     (31, 2, 200, 320, 40),      # 961 px: 16 window elements per lane
     (33, 1, 200, 320, 24),      # beyond the wave-per-feature kernel: slice kernel with LDS template
 ])
