@@ -62,6 +62,7 @@ def parse():
                          "(streams/gpus per GPU, stepped together through gklt_multistream, one frame of "
                          "each per call, no lookahead); a step is then one frame of every stream")
     ap.add_argument("--track-waves", type=int, default=0, help="wavefronts per tracker launch (0 = library default)")
+    ap.add_argument("--track-impl", type=int, default=0, help="gklt_ctx_set_track_impl (A/B runs; 0 = default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -434,6 +435,7 @@ def main():
     gp = klt.make_params(**params_kw)
     ctx = klt.Context(0 if a.share_gpu else local_rank, gp)
     ctx.set_track_waves(a.track_waves)
+    ctx.set_track_impl(a.track_impl)
     if a.streams > 0:
         return main_multistream(a, ctx, cfg, gp, dist, rank, world)
 
