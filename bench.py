@@ -500,6 +500,22 @@ def main():
     ctx.profile_enable(False)
     p_tracked, p_iters = st.fl.stats(reset=True)
 
+    # ---- the level kernels alone (empty list: no tracker launch shares the CUs): how far the
+    # build is from its own HBM bound when nothing competes with it.  Reported beside the roofline
+    # block, never used for `value`.
+    alone = {}
+    if B and not a.main_only:
+        st.seeds = (np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
+        st.la.upload_features(*st.seeds)  # (the periodic re-seed then uploads the empty list too)
+        st.run(2 * B)
+        st.sync()
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        st.run(8 * B)
+        st.sync()
+        alone = {k: ms / cnt * 1e3 for k, (ms, cnt) in ctx.profile_get().items() if cnt}
+        ctx.profile_enable(False)
+
     if not B:
         fa1 = (tracked, dt, a.steps)
         if not a.main_only:
@@ -564,6 +580,11 @@ def main():
                      "traffic": pmc_traffic * fpl if pmc_traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": per_kernel[dom]["avg_us"],
                      "frames_per_launch": fpl,
+                     "level0_alone": ({"avg_launch_us": alone["level0"],
+                                       "achieved": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9,
+                                       "frac": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                       "what": "k_level<u8> with no tracker launch sharing the CUs (empty "
+                                               "feature list), same batches"} if "level0" in alone else None),
                      "note": "dominant kernel by total time in the profiled leg; tracker bytes = "
                              "[4*N*L + 3*iters] footprints of (w+1)(h+1)*4 B per frame "
                              "(iters/feature/frame=%.2f), level-0 bytes = W*H*(1+12+1) per frame; "
