@@ -45,7 +45,7 @@ def _pmc_bytes(fetch_kib, write_kib, frames):
 
 
 PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(121800.0, 1264.0, 16),
-               ("C2", "level0"): _pmc_bytes(76570.0, 421200.0, 16)}
+               ("C2", "level0"): _pmc_bytes(76580.0, 421200.0, 16)}
 
 
 def parse():
