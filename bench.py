@@ -599,8 +599,10 @@ def main():
         threads = min(16, len(os.sched_getaffinity(0)))
         ncpu = a.cpu_frames or {"C2": 160, "Cship": 160, "C3": 48}.get(a.config, 24)
         v, cdt = cpu_baseline(params_kw, frames, seeds, ncpu, threads)
+        v1, cdt1 = cpu_baseline(params_kw, frames, seeds, max(ncpu // 16, 4), 1)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads,
                                "kind": "port",
+                               "one_core": {"value": v1, "sample": "%d frames, %.1f s wall" % (max(ncpu // 16, 4), cdt1)},
                                "sample": "%d frames of the same stream (pyramid + track), oracle/ C "
                                          "restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
     st.close()
