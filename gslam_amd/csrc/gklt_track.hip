@@ -510,10 +510,10 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   // ordered reduction of nq quantities whose per-element products sit in prod[q][0..NA)
   auto reduce = [&](int nq, float (&tot)[5]) {
     __syncthreads();
+    float acc = 0.f;
     if (lane < nq * SL) {
       const int q = lane >> 3, k = lane & 7;
       const float *p = prod + q * NA + k;
-      float acc = 0.f;
       if constexpr (NEC > 0 && NEC <= 16) {
         float t[NEC];
 #pragma unroll
@@ -531,18 +531,20 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
             if (j0 + u < nec) acc = acc + t[u];
         }
       }
-      part[lane] = acc;
     }
-    __syncthreads();
-    float t = 0.f;
-    if (lane < nq) {
-      const float4 lo = *reinterpret_cast<const float4 *>(part + lane * SL);
-      const float4 hi = *reinterpret_cast<const float4 *>(part + lane * SL + 4);
-      t = ((((((lo.x + lo.y) + lo.z) + lo.w) + hi.x) + hi.y) + hi.z) + hi.w;
-    }
+    // The 8 partials of quantity q sit in lanes 8q .. 8q+7 and are added left to right
+    // (LK.hpp:143-145) without leaving the registers: seven steps s[l] = s[l-1] + acc[l] (DPP
+    // row_shr:1).  After step i lane 8q+i holds ((p0 + p1) + ...) + p_i, so lane 8q+7 ends with
+    // the reference's sum; what the other lanes hold meanwhile never enters that chain.
+    float t = acc;
+#pragma unroll
+    for (int i = 1; i < SL; ++i)
+      t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t),
+                                                                 0x111 /* row_shr:1 */, 0xf, 0xf, true)) +
+          acc;
 #pragma unroll
     for (int q = 0; q < 5; ++q)
-      tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), q));
+      tot[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), q * SL + SL - 1));
   };
 
   // The grid is capped (launch_track_frames) so that a launch never takes every wave slot of
