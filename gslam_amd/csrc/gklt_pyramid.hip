@@ -444,9 +444,14 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // The fused level kernel works on 64 x 32 tiles with 8 waves (4 output rows per wave): compared
 // with 64 x 16 the halo rows (2 * (HI + R0) = 14 at C2) are shared by twice as many outputs, which
 // takes ~17 % of the kernel's VALU work away.
-constexpr int LTH = 32, LNT = 512, LNW = LNT / 64;
+// Workgroups of 8 waves (4 output rows per wave) for single-frame launches, whose dependent chain
+// of four launches wants short workgroups, and of 4 waves (8 rows per wave) for batched launches:
+// those run next to a tracker launch that holds 16 of a CU's 32 wave slots, and three 4-wave
+// workgroups fit beside it where only two 8-wave ones do (LDS allows three either way): level 0
+// 244 -> 219 us per 16-frame launch while overlapped, C2 191 -> 201 M.
+constexpr int LTH = 32;
 
-template <int R0, int HI>
+template <int R0, int HI, int LNT>
 struct LevelGeom {
   static constexpr int HIP = (HI + 3) / 4 * 4;    // halo of I padded to whole float4 groups
   static constexpr int AW = TW + 2 * HIP;         // row length of A and I
@@ -474,11 +479,12 @@ __device__ __forceinline__ int reflect101_near(int i, int n, bool wide) {
 
 // out[ROWS][WIDTH] <- src[reflect(ys + ty)][reflect(xs + tx)], every load issued before the
 // first LDS store.
-template <int ROWS, int WIDTH, typename SrcT>
+template <int ROWS, int WIDTH, int LNT, typename SrcT>
 __device__ __forceinline__ void stage_region(const SrcT *__restrict__ src, int stride, int w, int h,
                                              int xs, int ys, float *out) {
   // the wave index as a scalar: row indices, reflections and row pointers then live in SGPRs
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int LNW = LNT / 64;
   constexpr int PER = (ROWS + LNW - 1) / LNW;
   // Images of at least 192 px per side (uniform test): every staged index is less than one
   // image size outside [0, n), so one reflection (two selects) suffices; smaller images take
@@ -508,7 +514,7 @@ __device__ __forceinline__ void stage_region(const SrcT *__restrict__ src, int s
 // The same for a u8 source whose staged columns all lie inside the image (no reflection in x) and
 // whose rows are 4-byte aligned: one dword (4 pixels) per load and one ds_write_b128 per store
 // instead of four byte loads, four conversions' worth of addressing and four ds_write_b32.
-template <int ROWS, int WIDTH>
+template <int ROWS, int WIDTH, int LNT>
 __device__ __forceinline__ void stage_region_u8x4(const uint8_t *__restrict__ src, int stride, int h,
                                                   int xs, int ys, float *out) {
   static_assert(WIDTH % 4 == 0, "whole dwords per staged row");
@@ -552,7 +558,7 @@ struct LevelIO {
   float *down[GKLT_MAX_LOOKAHEAD];
 };
 
-template <typename SrcT, int R0, int RP, int RG, bool DOWN>
+template <typename SrcT, int R0, int RP, int RG, bool DOWN, int LNT>
 __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, int h, Taps s0,
                                               Taps pyr, Taps g, Taps d,
                                               float *__restrict__ img_out, int w2, int h2) {
@@ -560,7 +566,8 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
   Texel *__restrict__ tex = io.tex[blockIdx.z];
   float *__restrict__ down = io.down[blockIdx.z];
   constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
-  using G = LevelGeom<R0, HI>;
+  using G = LevelGeom<R0, HI, LNT>;
+  constexpr int RPW = LTH / (LNT / 64);  // output rows per wave
   constexpr int GH = LTH + 2 * RG;  // rows of the gradient row pass
   constexpr int GOFF = HI - RG;    // its first row inside I
   extern __shared__ __align__(16) float lds[];
@@ -576,12 +583,12 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
     if constexpr (sizeof(SrcT) == 1) {
       // uniform per block: interior columns and dword-aligned rows take the 4-pixel loads
       if (xs >= 0 && xs + G::SW <= w && ((stride | (int)(reinterpret_cast<size_t>(src) & 3)) & 3) == 0)
-        stage_region_u8x4<G::SH, G::SW>(reinterpret_cast<const uint8_t *>(src), stride, h, xs,
+        stage_region_u8x4<G::SH, G::SW, LNT>(reinterpret_cast<const uint8_t *>(src), stride, h, xs,
                                         y0 - HI - R0, S);
       else
-        stage_region<G::SH, G::SW>(src, stride, w, h, xs, y0 - HI - R0, S);
+        stage_region<G::SH, G::SW, LNT>(src, stride, w, h, xs, y0 - HI - R0, S);
     } else {
-      stage_region<G::SH, G::SW>(src, stride, w, h, xs, y0 - HI - R0, S);
+      stage_region<G::SH, G::SW, LNT>(src, stride, w, h, xs, y0 - HI - R0, S);
     }
     __syncthreads();
     constexpr int GPR = G::AW / 4;
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
     }
     __syncthreads();
   } else {
-    stage_region<G::IHh, G::AW>(src, stride, w, h, x0 - G::HIP, y0 - HI, I);
+    stage_region<G::IHh, G::AW, LNT>(src, stride, w, h, x0 - G::HIP, y0 - HI, I);
     __syncthreads();
   }
 
@@ -648,19 +655,19 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
   __syncthreads();
 
   {  // gradient column pass -> texels
-    float vd[4 + 2 * RG], vg[4 + 2 * RG];
+    float vd[RPW + 2 * RG], vg[RPW + 2 * RG];
 #pragma unroll
-    for (int i = 0; i < 4 + 2 * RG; ++i) {
-      vd[i] = rowd[(4 * wave + i) * TW + lane];
-      vg[i] = rowg[(4 * wave + i) * TW + lane];
+    for (int i = 0; i < RPW + 2 * RG; ++i) {
+      vd[i] = rowd[(RPW * wave + i) * TW + lane];
+      vg[i] = rowg[(RPW * wave + i) * TW + lane];
     }
     const int x = x0 + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int y = y0 + 4 * wave + j;
+    for (int j = 0; j < RPW; ++j) {
+      const int y = y0 + RPW * wave + j;
       const float gx = corr_win<RG, +1>(vd, RG + j, g);
       const float gy = corr_win<RG, -1>(vg, RG + j, d);
-      const float ic = I[(4 * wave + j + HI) * G::AW + G::HIP + lane];
+      const float ic = I[(RPW * wave + j + HI) * G::AW + G::HIP + lane];
       if (x < w && y < h) {
         // streaming store: the texels are next read by a tracker launch at least one build
         // later, and must not evict the window footprints a concurrent tracker gathers from L2
@@ -673,18 +680,18 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
     }
   }
   if constexpr (DOWN) {  // pyramid column pass -> 2x2 mean -> next level
-    float v[4 + 2 * RP], o[4];
+    float v[RPW + 2 * RP], o[RPW];
 #pragma unroll
-    for (int i = 0; i < 4 + 2 * RP; ++i) v[i] = rowp[(4 * wave + i + HI - RP) * TW + lane];
+    for (int i = 0; i < RPW + 2 * RP; ++i) v[i] = rowp[(RPW * wave + i + HI - RP) * TW + lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = corr_win<RP, +1>(v, RP + j, pyr);
+    for (int j = 0; j < RPW; ++j) o[j] = corr_win<RP, +1>(v, RP + j, pyr);
     const int x = x0 / 2 + (lane >> 1);
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < RPW / 2; ++jj) {
       const float a = o[2 * jj], c = o[2 * jj + 1];
       const float b = __shfl_xor(a, 1), e = __shfl_xor(c, 1);
       const float m = (((a + b) + c) + e) * 0.25f;
-      const int y = y0 / 2 + 2 * wave + jj;
+      const int y = y0 / 2 + RPW / 2 * wave + jj;
       if (!(lane & 1) && x < w2 && y < h2) down[(size_t)y * w2 + x] = m;
     }
   }
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
 template <int R0, int RP, int RG, bool DOWN>
 constexpr size_t level_lds() {
   constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
-  using G = LevelGeom<R0, HI>;
+  using G = LevelGeom<R0, HI, 512>;  // the sizes used here do not depend on the workgroup size
   constexpr size_t p1 = R0 > 0 ? (size_t)G::SH * (G::SW + G::AW) : 0;
   constexpr size_t p2 = 2 * (size_t)(LTH + 2 * RG) * TW + (DOWN ? (size_t)G::IHh * TW : 0);
   return sizeof(float) * ((size_t)G::IHh * G::AW + (p1 > p2 ? p1 : p2));
@@ -829,12 +836,16 @@ template <typename SrcT, int R0, bool DOWN>
 int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const LevelIO &io, int nframes,
                       int stride, int w, int h, const Taps &s0, const Taps &pyr, const Taps &g,
                       const Taps &d, float *img_out, int w2, int h2) {
-  auto kern = k_level<SrcT, R0, 5, 3, DOWN>;
   constexpr size_t lds = level_lds<R0, 5, 3, DOWN>();
   static_assert(lds <= 64 * 1024, "fused level kernel fits the LDS a launch gets without opt-in");
   dim3 grid((w + TW - 1) / TW, (h + LTH - 1) / LTH, nframes);
   ProfScope ps(ctx, s, prof_id);
-  hipLaunchKernelGGL(kern, grid, dim3(LNT), lds, s, io, stride, w, h, s0, pyr, g, d, img_out, w2, h2);
+  if (nframes > 1)  // batched: 4-wave workgroups (see LTH)
+    hipLaunchKernelGGL((k_level<SrcT, R0, 5, 3, DOWN, 256>), grid, dim3(256), lds, s, io, stride, w, h,
+                       s0, pyr, g, d, img_out, w2, h2);
+  else
+    hipLaunchKernelGGL((k_level<SrcT, R0, 5, 3, DOWN, 512>), grid, dim3(512), lds, s, io, stride, w, h,
+                       s0, pyr, g, d, img_out, w2, h2);
   GKLT_HIP(hipGetLastError());
   return 0;
 }
