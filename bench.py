@@ -44,8 +44,8 @@ def _pmc_bytes(fetch_kib, write_kib, frames):
     return (2.0 * fetch_kib + write_kib) * 1024.0 / frames
 
 
-PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(121800.0, 1264.0, 16),
-               ("C2", "level0"): _pmc_bytes(76580.0, 421200.0, 16)}
+PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(122400.0, 1270.0, 16),
+               ("C2", "level0"): _pmc_bytes(76630.0, 421200.0, 16)}
 
 
 def parse():
