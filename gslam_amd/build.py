@@ -1,20 +1,26 @@
-"""Builds gslam_amd/libgklt.so (HIP, gfx950 only) in-tree with hipcc.  No GPU needed."""
+"""Builds gslam_amd/libgklt.so (HIP, gfx950 only) in-tree with hipcc.  No GPU needed.
+
+Each translation unit is compiled to an object under gslam_amd/build/ (in parallel, only when it
+or a header changed) and the objects are linked into the shared library."""
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgklt.so")
-SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip", "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip",
-           "gklt_select.hip"]
+SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip",
+           "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip", "gklt_select.hip",
+           "gklt_seed.hip", "gklt_ingest.hip", "gklt_ransac.hip"]
 HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h")]
 
 # -ffp-contract=off: the reference's arithmetic is unfused AVX (no FMA); fusing mul+add on the
 # GPU would change borderline status flags.  Correctly rounded fp32 divide/sqrt is hipcc's
 # default and is requested explicitly because parity depends on it.
 FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-result",
 ]
 
@@ -23,22 +29,43 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def stale():
-    if not os.path.exists(LIB):
+def _deps():
+    return [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.basename(src) + ".o")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def stale():
+    return _newer(LIB, sources() + _deps())
 
 
 def build(force=False, verbose=False, extra=()):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip"] + sources() + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for src in sources():
+        if force or extra or _newer(_obj(src), [src] + _deps()):
+            jobs.append([hipcc] + FLAGS + list(extra) + ["-x", "hip", "-c", src, "-o", _obj(src)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in sources()] + ["-o", LIB])
     return LIB
 
 

@@ -1,18 +1,21 @@
 // Coarse-to-fine iterative Lucas-Kanade for gfx950 -- replaces KLTTrackFeatures / KLTInvoker /
 // _trackFeature and the AVX helpers under them (LK.hpp:56-208, 413-669, 825-1046).
 //
-// Mapping: one feature per 8-lane slice of a wavefront (8 features per wave64).  Lane k of a
-// slice owns window elements k, k+8, k+16, ... in row-major window order -- exactly the
-// elements AVX lane k accumulates in the reference (LK.hpp:127-166) -- so each lane's partial
-// sum is built in the reference's order, and the 8 partials are then added left to right
-// (LK.hpp:143-145,163-164,207) after a cross-lane exchange inside the slice.  With the
-// translation unit built -ffp-contract=off every fp32 operation rounds as the reference's
-// unfused AVX code does, which makes positions and status flags reproducible bit for bit.
-//
-// All pyramid levels and all Newton iterations of a feature run inside one launch.  The
-// template patch (I, gx, gy of frame 1) lives in registers for the instantiated window sizes
-// and in LDS for the generic kernel.  Each bilinear tap is one 12-byte load of an (I,gx,gy)
-// texel (layout written by gklt_pyramid.hip).
+// Two mappings, bit-identical to each other and to the oracle:
+//  * k_track_w (the default, second half of this file): ONE FEATURE PER WAVEFRONT, window
+//    element i -> lane i % 64, the reference's AVX summation order rebuilt through LDS chain
+//    sums; 7x7 windows hold the bilinear footprint in registers (one load per lane and patch),
+//    windows >= 15 px stage it in LDS.  Multi-frame (lookahead) and multi-stream launches.
+//  * k_track (track_impl 1, and the fallback for windows the wave kernel cannot hold): one
+//    feature per 8-lane slice (8 features per wave64).  Lane k of a slice owns window elements
+//    k, k+8, k+16, ... in row-major window order -- exactly the elements AVX lane k accumulates
+//    in the reference (LK.hpp:127-166) -- and the 8 partials are added left to right
+//    (LK.hpp:143-145,163-164,207) after a cross-lane exchange inside the slice.
+// With the translation unit built -ffp-contract=off every fp32 operation rounds as the
+// reference's unfused AVX code does, which makes positions and status flags reproducible bit
+// for bit.  All pyramid levels and all Newton iterations of a feature run inside one launch.
+// Each bilinear tap is one 12-byte load of an (I,gx,gy) texel (layout written by
+// gklt_pyramid.hip).
 #include <algorithm>
 
 #include "gklt_internal.h"
@@ -187,9 +190,11 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
   bool descending = alive;
 
   for (int r = a.nlevels - 1; r >= 0; --r) {  // LK.hpp:859-881
+    // After SMALL_DET / OOB the reference leaves the loop (LK.hpp:879-880) and tests
+    // _outOfBounds on xlocout at the scale of the level it broke at: stop scaling too.
+    if (!descending) continue;
     xloc *= a.ss; yloc *= a.ss;
     xo *= a.ss; yo *= a.ss;
-    if (!descending) continue;
 
     // ---- _trackFeature, LK.hpp:413-669 ----
     const TrackLevel L = a.lv[r];

@@ -202,3 +202,67 @@ def test_lookahead_wavefronts_take_several_features(klt, ok, gpu_ctx, waves):
         la.close()
         for _, p in outs:
             gpu_ctx.pinned_free(p)
+
+
+@pytest.mark.parametrize("waves", [0, 37])
+def test_lookahead_11x11_capped_launch(klt, ok, gpu_ctx, waves):
+    """The multi-frame 11x11 launch of BASELINE C3 (two window elements per lane, 16-element
+    chains) with fewer wavefronts than features, so each follows several features through the
+    batch; 5 levels as C3."""
+    H, W, n, B = 288, 512, 900, 6
+    f = _stream(H, W, B + 1, seed=17)
+    gp = klt.make_params(window=11, levels=5, border=40)
+    op = ok.make_params(window=11, levels=5, border=40)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    val[13] = -2
+    ref = _oracle_lists(ok, op, f, x, y, val)
+    gpu_ctx.set_track_waves(waves)
+    la = klt.Lookahead(gpu_ctx, W, H, n, B)
+    outs = [gpu_ctx.pinned_array((3, n), np.float32) for _ in range(B)]
+    try:
+        la.upload_features(x, y, val)
+        la.start(f[0])
+        la.submit(f[1:B + 1], [o[1] for o in outs])
+        la.flush()
+        for k in range(B):
+            _same(outs[k][0], ref[k], "frame %d" % (k + 1))
+        assert (ref[-1][2] == 0).mean() > 0.8
+    finally:
+        gpu_ctx.set_track_waves(0)
+        la.close()
+        for _, p in outs:
+            gpu_ctx.pinned_free(p)
+
+
+def test_lookahead_full_size_c3(klt, ok, gpu_ctx):
+    """BASELINE C3 as bench.py runs it: 4K frames, 16000 features, 5 levels, 11x11, batches through
+    gklt_lookahead with the default cap of 4096 wavefronts (each follows ~4 features)."""
+    H, W, n, B = 2160, 3840, 16000, 3
+    T = synth.base_texture(H, W, seed=23)
+    f = [synth.render_frame(T, H, W, k, seed=23) for k in range(B + 1)]
+    gp = klt.make_params(window=11, levels=5)
+    op = ok.make_params(window=11, levels=5)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx, nx=160, ny=100)
+    val = np.zeros(n, np.int32)
+    ok.set_threads(8)
+    try:
+        ref = _oracle_lists(ok, op, f, x, y, val)
+    finally:
+        ok.set_threads(1)
+    la = klt.Lookahead(gpu_ctx, W, H, n, B)
+    outs = [gpu_ctx.pinned_array((3, n), np.float32) for _ in range(B)]
+    try:
+        la.upload_features(x, y, val)
+        la.start(f[0])
+        la.submit(f[1:B + 1], [o[1] for o in outs])
+        la.flush()
+        for k in range(B):
+            _same(outs[k][0], ref[k], "frame %d" % (k + 1))
+        assert (ref[-1][2] == 0).mean() > 0.9
+    finally:
+        la.close()
+        for _, p in outs:
+            gpu_ctx.pinned_free(p)

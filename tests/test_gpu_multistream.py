@@ -42,9 +42,10 @@ def _same(x, y, v, ref, what):
     (3, True, False, 11, 2, 0),    # pageable host_out: copy path
     (18, True, True, 7, 2, 0),     # more streams than one batched build launch takes (16)
     (2, False, True, 21, 2, 0),    # LDS-staged footprint variant of the tracker
+    (64, True, True, 7, 4, 0),     # BASELINE C4's stream count: four 16-stream build launches, 64-stream slot space
 ])
 def test_multistream_matches_oracle(klt, ok, gpu_ctx, S, device_frames, pinned, window, levels, waves):
-    H, W, cap, nfr = (120, 200, 150, 5) if S <= 5 else (96, 160, 60, 4)
+    H, W, cap, nfr = (120, 200, 150, 5) if S <= 5 else ((96, 160, 60, 4) if S < 64 else (192, 320, 90, 4))
     gp = klt.make_params(window=window, levels=levels)
     op = ok.make_params(window=window, levels=levels)
     gpu_ctx.set_params(gp)

@@ -130,6 +130,29 @@ def test_track_status_codes(klt, ok, gpu_ctx):
     assert (got[0][lost] == -1.0).all() and (got[1][lost] == -1.0).all()  # LK.hpp:888-910
 
 
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+def test_track_descent_break_keeps_coarse_scale(klt, ok, gpu_ctx, impl):
+    """SMALL_DET at a coarse level r > 0 ends the descent (LK.hpp:879-880) and _outOfBounds
+    (LK.hpp:890-899) then sees xlocout still at level-r scale: a flat patch near the left / top
+    border comes back KLT_OOB, not KLT_SMALL_DET.  Every tracker mapping, 3 levels."""
+    H, W = 200, 320
+    T = synth.base_texture(H, W, seed=3)
+    f0 = synth.render_frame(T, H, W, 0, seed=3, noise_sigma=0).copy()
+    f1 = synth.render_frame(T, H, W, 1, seed=3, noise_sigma=0).copy()
+    f0[0:180, 0:110] = 90; f1[0:180, 0:110] = 90       # flat down to level 2
+    #            left border  top border  inside     textured
+    x = np.array([20.0,        60.0,       60.0,      200.5], np.float32)
+    y = np.array([100.0,       28.0,       100.0,     120.25], np.float32)
+    val = np.zeros(4, np.int32)
+    gpu_ctx.set_track_impl(impl)
+    try:
+        got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 7, 3, x, y, val, border=8)
+    finally:
+        gpu_ctx.set_track_impl(0)
+    _assert_same(got, ref)
+    assert list(got[2]) == [klt.KLT_OOB, klt.KLT_OOB, klt.KLT_SMALL_DET, klt.KLT_TRACKED]
+
+
 def test_track_integer_positions_take_copy_path(klt, ok, gpu_ctx):
     """weights[0]==1.0 -> memcpy rows (LK.hpp:80-85)."""
     H, W = 135, 240
@@ -222,6 +245,63 @@ def test_full_size_c2_frame_pair(klt, ok, gpu_ctx):
     ok.set_threads(8)
     try:
         got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 7, 4, x, y, val)
+    finally:
+        ok.set_threads(1)
+    _assert_same(got, ref)
+    assert (got[2] == 0).mean() > 0.95
+
+
+def test_full_size_c3_frame_pair(klt, ok, gpu_ctx):
+    """BASELINE C3 at full size: 3840x2160, 16000 features, 5 levels, 11x11, border 160."""
+    H, W, n = 2160, 3840, 16000
+    T = synth.base_texture(H, W)
+    f0, f1 = synth.render_frame(T, H, W, 0), synth.render_frame(T, H, W, 1)
+    p = ok.make_params(window=11, levels=5)
+    assert p.borderx == 160
+    x, y = synth.lattice_seeds(H, W, n, p.borderx, nx=160, ny=100)
+    val = np.zeros(n, np.int32)
+    ok.set_threads(8)
+    try:
+        got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 11, 5, x, y, val)
+    finally:
+        ok.set_threads(1)
+    _assert_same(got, ref)
+    assert (got[2] == 0).mean() > 0.95
+
+
+def test_full_size_c3_pyramid(klt, ok, gpu_ctx):
+    """The 5-level pyramid of a 4K frame (sigma0 = 1.1 for the 11x11 window), every plane exact."""
+    H, W = 2160, 3840
+    T = synth.base_texture(H, W, seed=77)
+    f0 = synth.render_frame(T, H, W, 3, seed=77)
+    gpu_ctx.set_params(klt.make_params(window=11, levels=5))
+    op = ok.make_params(window=11, levels=5)
+    ok.set_threads(8)
+    p0 = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(f0)
+        ref = ok.compute_pyramid(op, f0)
+        for i, r in enumerate(ref):
+            g = p0.plane(i // 3, i % 3)
+            assert g.shape == r.shape
+            assert (g.view(np.uint32) == np.asarray(r, np.float32).view(np.uint32)).all(), "plane %d" % i
+    finally:
+        ok.set_threads(1)
+        p0.close()
+
+
+def test_full_size_cship_frame_pair(klt, ok, gpu_ctx):
+    """The as-shipped configuration (Settings.h:65 DEBUG, System.cpp:326-344: 21x21, 2 levels,
+    border 50; list of 2000, System.cpp:117) at 1080p -- the substitute for BASELINE config 1,
+    whose 'robot' sequence is not in the reference repository.  LDS-staged footprint kernel."""
+    H, W, n = 1080, 1920, 2000
+    T = synth.base_texture(H, W, seed=11)
+    f0, f1 = synth.render_frame(T, H, W, 0, seed=11), synth.render_frame(T, H, W, 1, seed=11)
+    x, y = synth.lattice_seeds(H, W, n, 50, nx=60, ny=34)
+    val = np.zeros(n, np.int32)
+    ok.set_threads(8)
+    try:
+        got, ref = _run_pair(klt, ok, gpu_ctx, f0, f1, 21, 2, x, y, val, border=50)
     finally:
         ok.set_threads(1)
     _assert_same(got, ref)
