@@ -209,10 +209,10 @@ def test_lookahead_11x11_capped_launch(klt, ok, gpu_ctx, waves):
     """The multi-frame 11x11 launch of BASELINE C3 (two window elements per lane, 16-element
     chains) with fewer wavefronts than features, so each follows several features through the
     batch; 5 levels as C3."""
-    H, W, n, B = 288, 512, 900, 6
+    H, W, n, B = 480, 768, 900, 6     # coarsest level 30 x 48: border 96 keeps windows inside it
     f = _stream(H, W, B + 1, seed=17)
-    gp = klt.make_params(window=11, levels=5, border=40)
-    op = ok.make_params(window=11, levels=5, border=40)
+    gp = klt.make_params(window=11, levels=5, border=96)
+    op = ok.make_params(window=11, levels=5, border=96)
     gpu_ctx.set_params(gp)
     x, y = synth.lattice_seeds(H, W, n, gp.borderx)
     val = np.zeros(n, np.int32)
