@@ -10,8 +10,11 @@ namespace gklt {
 int fix_window(gklt_params *p);  // gklt_host.cpp
 
 // ------------------------------------------------------------------ profiling brackets
+// Set by entry points that must not allocate (profiling brackets may create events).
+static thread_local bool t_no_profile = false;
+
 ProfScope::ProfScope(gklt_ctx *c, hipStream_t st, int kid) : ctx(c), s(st), id(kid) {
-  if (!ctx || !ctx->profiling) return;
+  if (!ctx || !ctx->profiling || t_no_profile) return;
   std::lock_guard<std::mutex> lk(ctx->mu);
   auto take = [&]() {
     hipEvent_t e = nullptr;
@@ -89,6 +92,16 @@ static int check_params(const gklt_params &p) {
 
 using namespace gklt;
 
+// Scratch of gklt_track_noalloc: tracker counters (GKLT_STAT_SHARDS x {tracked, iterations}
+// 64-bit words) followed by the staged list x[MAX] | y[MAX] | val[MAX].  One copy per GPU, held
+// until the process ends.  In host code the name `scratch` is only a handle for
+// hipGetSymbolAddress: kernels and copies get the per-device address kept in gklt_ctx.
+namespace {
+constexpr size_t kNoallocStatBytes = 2 * GKLT_STAT_SHARDS * sizeof(unsigned long long);
+constexpr size_t kNoallocBytes = kNoallocStatBytes + 3 * sizeof(float) * (size_t)GKLT_NOALLOC_MAX_FEATURES;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNoallocBytes];
+
 
 // ====================================================================== context
 extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
@@ -113,6 +126,8 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
   GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
   GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
+  // this device's copy of the allocation-free entry point's scratch array
+  GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
   *out = c;
   return 0;
 }
@@ -656,6 +671,54 @@ extern "C" int gklt_track(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2, int
     GKLT_HIP(hipMemcpyAsync(vec3, ctx->d_vec, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
   }
   GKLT_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// KLTTrackFeatures for callers that cannot allocate: the list is staged in the file-scope
+// `scratch` array of this GPU instead of a hipMalloc'd list; no hipMalloc / hipFree / event
+// creation on this path.
+extern "C" int gklt_track_noalloc(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2, int n,
+                                  float *x, float *y, int *val, uint64_t *tracked) {
+  if (!ctx || !p1 || !p2 || p1->ctx != ctx || p2->ctx != ctx || n < 0) return GKLT_EINVAL;
+  if (tracked) *tracked = 0;
+  if (n == 0) return 0;
+  if (!x || !y || !val) return GKLT_EINVAL;
+  if (n > GKLT_NOALLOC_MAX_FEATURES) {
+    set_error("gklt_track_noalloc: %d features exceed GKLT_NOALLOC_MAX_FEATURES (%d); use gklt_track",
+              n, GKLT_NOALLOC_MAX_FEATURES);
+    return GKLT_ECAPACITY;
+  }
+  if (!ctx->noalloc_scratch) {
+    set_error("gklt_track_noalloc: the context holds no scratch address");
+    return GKLT_EINVAL;
+  }
+  if (int rc = use_device(ctx)) return rc;
+  hipStream_t s = ctx->s_trk;
+  unsigned char *base = static_cast<unsigned char *>(ctx->noalloc_scratch);
+  unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(base);
+  float *dx = reinterpret_cast<float *>(base + kNoallocStatBytes);
+  float *dy = dx + GKLT_NOALLOC_MAX_FEATURES;
+  int *dv = reinterpret_cast<int *>(dy + GKLT_NOALLOC_MAX_FEATURES);
+  // the array keeps the last call's contents: the counters must start at zero
+  GKLT_HIP(hipMemsetAsync(d_stats, 0, kNoallocStatBytes, s));
+  GKLT_HIP(hipMemcpyAsync(dx, x, sizeof(float) * n, hipMemcpyDefault, s));
+  GKLT_HIP(hipMemcpyAsync(dy, y, sizeof(float) * n, hipMemcpyDefault, s));
+  GKLT_HIP(hipMemcpyAsync(dv, val, sizeof(int) * n, hipMemcpyDefault, s));
+  t_no_profile = true;
+  const int rc = track_common(ctx, p1, p2, n, dx, dy, dv, nullptr, nullptr, nullptr, d_stats);
+  t_no_profile = false;
+  if (rc) return rc;
+  unsigned long long h[2 * GKLT_STAT_SHARDS];
+  GKLT_HIP(hipMemcpyAsync(x, dx, sizeof(float) * n, hipMemcpyDefault, s));
+  GKLT_HIP(hipMemcpyAsync(y, dy, sizeof(float) * n, hipMemcpyDefault, s));
+  GKLT_HIP(hipMemcpyAsync(val, dv, sizeof(int) * n, hipMemcpyDefault, s));
+  GKLT_HIP(hipMemcpyAsync(h, d_stats, sizeof h, hipMemcpyDeviceToHost, s));
+  GKLT_HIP(hipStreamSynchronize(s));
+  if (tracked) {
+    unsigned long long t = 0;
+    for (int i = 0; i < GKLT_STAT_SHARDS; ++i) t += h[2 * i];
+    *tracked = t;
+  }
   return 0;
 }
 

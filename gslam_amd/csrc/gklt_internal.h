@@ -68,6 +68,7 @@ struct gklt_ctx {
   int d_nv_capacity = 0;
   double *d_rot = nullptr;  // row rotations + invK of the rotate-and-normalise epilogue
   int d_rot_capacity = 0;   // in doubles
+  void *noalloc_scratch = nullptr;  // this GPU's address of gklt_api.hip's `scratch` array
   // profiling
   int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)

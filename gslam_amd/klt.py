@@ -587,6 +587,19 @@ def KLTTrackFeatures(ctx, pyr1, pyr2, x, y, val, invK=None):
     return x, y, val, norm, vec
 
 
+NOALLOC_MAX_FEATURES = 32768
+
+
+def track_noalloc(ctx, pyr1, pyr2, x, y, val):
+    """gklt_track_noalloc: KLTTrackFeatures without device allocations -> (x, y, val, tracked)."""
+    x = np.array(x, np.float32)
+    y = np.array(y, np.float32)
+    val = np.array(val, np.int32)
+    t = C.c_uint64()
+    _check(lib().gklt_track_noalloc(ctx.h, pyr1.h, pyr2.h, len(x), _fp(x), _fp(y), _ip(val), C.byref(t)))
+    return x, y, val, t.value
+
+
 def track_flist(ctx, pyr1, pyr2, fl):
     _check(lib().gklt_track_flist(ctx.h, pyr1.h, pyr2.h, fl.h))
 

@@ -156,6 +156,19 @@ int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt
 int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked, uint64_t *iterations,
                      int reset);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): gklt_track() on host
+ * or device x / y / val arrays of n <= GKLT_NOALLOC_MAX_FEATURES entries, with the list staging and
+ * the tracker counters in a fixed array that libgklt.so holds on every GPU it runs on (388 KiB,
+ * until the process ends) instead of hipMalloc'd buffers; the call makes no hipMalloc / hipFree
+ * and creates no events (kernel profiling brackets are skipped).  Results are those of gklt_track
+ * bit for bit; *tracked (may be NULL) = features that ended KLT_TRACKED.  More features:
+ * GKLT_ECAPACITY.  Synchronous.  All calls on one GPU share that GPU's array: calls that overlap
+ * on one GPU (two host threads, two contexts on one device) race -- serialise them. */
+#define GKLT_NOALLOC_MAX_FEATURES 32768
+int gklt_track_noalloc(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, int n, float *x,
+                       float *y, int *val, uint64_t *tracked);
+
 /* ---- S1-S6: Shi-Tomasi selection (selectGoodFeatures.hpp, System.cpp:385-392) ---- */
 
 enum { GKLT_SELECT_ALL = 0, GKLT_REPLACE_SOME = 1 };                         /* selectionMode, :34 */

@@ -1,0 +1,74 @@
+"""gklt_track_noalloc (the entry point for callers that cannot allocate: list staging and tracker
+counters in a fixed per-GPU array) against gklt_track, bit for bit, on two calls in a row, the
+second with a smaller input.  Collected last (test_zz_*): the round's end runs pytest -x."""
+import numpy as np
+import pytest
+
+from gslam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert (a[2] == b[2]).all()
+    assert (a[0].view(np.uint32) == b[0].view(np.uint32)).all()
+    assert (a[1].view(np.uint32) == b[1].view(np.uint32)).all()
+
+
+def test_track_noalloc_matches_gklt_track(klt, ok, gpu_ctx):
+    H, W = 270, 480
+    T = synth.base_texture(H, W, seed=29)
+    f = [synth.render_frame(T, H, W, k, seed=29) for k in range(3)]
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    ring = [klt.Pyramid(gpu_ctx, W, H) for _ in range(3)]
+    try:
+        for p, im in zip(ring, f):
+            p.build(im)
+        # first call: 1500 features, some lost / out of bounds from the start
+        x, y = synth.lattice_seeds(H, W, 1500, gp.borderx)
+        val = np.zeros(len(x), np.int32)
+        val[3] = -2
+        x[10] = 1.0
+        a = klt.track_noalloc(gpu_ctx, ring[0], ring[1], x, y, val)
+        b = klt.KLTTrackFeatures(gpu_ctx, ring[0], ring[1], x, y, val)
+        _same(a, b)
+        assert a[3] == int((b[2] == 0).sum()) and a[3] > 1000
+        ref = ok.track_features(op, ring[0].planes(), ring[1].planes(), x, y, val)
+        _same(a, ref)
+        # second call, smaller input (the array still holds the first call's tail and counters)
+        x2, y2 = synth.lattice_seeds(H, W, 333, gp.borderx, seed=5)
+        val2 = np.zeros(len(x2), np.int32)
+        a2 = klt.track_noalloc(gpu_ctx, ring[1], ring[2], x2, y2, val2)
+        b2 = klt.KLTTrackFeatures(gpu_ctx, ring[1], ring[2], x2, y2, val2)
+        _same(a2, b2)
+        assert a2[3] == int((b2[2] == 0).sum()) and 0 < a2[3] <= 333
+        # chained, as frames chain: output of the first call fed to the next pair
+        a3 = klt.track_noalloc(gpu_ctx, ring[1], ring[2], a[0], a[1], a[2])
+        b3 = klt.KLTTrackFeatures(gpu_ctx, ring[1], ring[2], b[0], b[1], b[2])
+        _same(a3, b3)
+        assert a3[3] == int((b3[2] == 0).sum())
+    finally:
+        for p in ring:
+            p.close()
+
+
+def test_track_noalloc_limits(klt, gpu_ctx):
+    H, W = 64, 96
+    gpu_ctx.set_params(klt.make_params(window=7, levels=2))
+    p0 = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(np.zeros((H, W), np.uint8))
+        n = klt.NOALLOC_MAX_FEATURES + 1
+        with pytest.raises(klt.GkltError, match="GKLT_NOALLOC_MAX_FEATURES"):
+            klt.track_noalloc(gpu_ctx, p0, p0, np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32))
+        x, y, v, t = klt.track_noalloc(gpu_ctx, p0, p0, [], [], [])
+        assert len(x) == 0 and t == 0
+        # the maximum size itself is accepted (flat image: every feature SMALL_DET or OOB)
+        n = klt.NOALLOC_MAX_FEATURES
+        x, y, v, t = klt.track_noalloc(gpu_ctx, p0, p0, np.full(n, 40, np.float32), np.full(n, 30, np.float32),
+                                       np.zeros(n, np.int32))
+        assert t == 0 and (v < 0).all()
+    finally:
+        p0.close()
