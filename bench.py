@@ -11,10 +11,13 @@ deeper preload).  --lookahead 0 times gklt_pipeline_step instead (one frame per 
 reference's preload depth of one); that mode is also what the latency leg and the
 "frame_at_a_time" block report.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|Cship]
-N > 1 is launched by torch.distributed.run, one rank per GPU.  Streams are independent, so
-there is no data-path collective; the harness's barrier / max-time / sum-count reductions run on
-CPU tensors (gloo).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C2|C3|Cship|C5] [--streams S]
+N > 1: one rank per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) the
+process is one of the N ranks; started plainly with --gpus N > 1 it is the launcher: before any HIP
+call it starts N fresh child processes (never an exec of a process that has touched the GPU),
+forwards rank 0's JSON line and fails if any child failed.  Streams are independent, so there is no
+data-path collective; the harness's barrier / max-time / sum-count reductions run on CPU tensors
+(gloo).
 
 libgklt.so (system ROCm 7.2 HIP runtime) is loaded BEFORE torch is imported: the torch wheel
 bundles an older libamdhip64 with the same soname, and HIP-graph capture crashes on it.
@@ -31,8 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from gslam_amd import klt, synth  # noqa: E402
-
-klt.lib()  # load libgklt.so (and the system HIP runtime) before anything can import torch
+# libgklt.so (and with it the system HIP runtime) is loaded by main() -- before torch can be
+# imported, and only in a process that is a rank: the launcher never touches HIP.
 
 RESEED_EVERY = 32
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -48,7 +51,7 @@ PMC_TRAFFIC = {("C2", "track"): _pmc_bytes(122400.0, 1270.0, 16),
                ("C2", "level0"): _pmc_bytes(76630.0, 421200.0, 16)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2048)
@@ -70,26 +73,98 @@ def parse():
                     help="timed + roofline legs only (for rocprofv3 runs: the frame-at-a-time and latency "
                          "legs launch the same kernels with one frame per launch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
-    return ap.parse_args()
+    ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive legs")
+    ap.add_argument("--select-variant", default="uniform", choices=["uniform", "plain", "round2"],
+                    help="--config C5: selector flavour run every frame")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="ranks print their rank / world / device and exit without touching the GPU "
+                         "(CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 outside torch.distributed.run: this process starts N ranks of this script as
+    fresh children (it has made no HIP call and makes none), relays rank 0's stdout and returns a
+    non-zero code if any rank failed."""
+    import subprocess
+
+    port = free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE, text=True))
+    rc = 0
+    outs = []
+    for r, p in enumerate(procs):
+        out, _ = p.communicate()
+        outs.append(out)
+        if p.returncode != 0:
+            print("bench.py: rank %d exited with code %d" % (r, p.returncode), file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode > 0 else 1)
+    if a.dry_launch:
+        sys.stdout.write("".join(outs))
+    else:
+        sys.stdout.write(outs[0])
+        for r, out in enumerate(outs[1:], 1):
+            if out.strip():
+                sys.stderr.write("[rank %d] %s" % (r, out))
+    sys.stdout.flush()
+    return rc
+
+
+class FrameStore:
+    """The synthetic frames of one stream where the timed region finds them: in HBM (`value` and
+    every roofline figure), or in page-locked host memory (the pcie_inclusive legs: the library
+    stages each frame H2D itself, as at the computePyramid boundary of SURVEY 3.1)."""
+
+    def __init__(self, ctx, frames, host=False):
+        self.ctx, self.host = ctx, host
+        self.W = frames[0].shape[1]
+        if host:
+            self.bufs = []
+            for f in frames:
+                arr, p = ctx.pinned_array(f.shape, np.uint8)
+                arr[:] = f
+                self.bufs.append(p)
+        else:
+            self.bufs = [ctx.device_upload(f) for f in frames]
+
+    def frame(self, t):
+        return (self.bufs[t % len(self.bufs)], self.W, 0 if self.host else 1)
+
+    def close(self):
+        for p in self.bufs:
+            (self.ctx.pinned_free if self.host else self.ctx.device_free)(p)
+        self.bufs = []
 
 
 class Stream:
     """One video stream on one GPU: frames in HBM, gklt_pipeline (3-deep pyramid ring + device
     feature list)."""
 
-    def __init__(self, ctx, cfg, frames, seeds):
+    def __init__(self, ctx, cfg, frames, seeds, host_frames=False):
         self.ctx, self.cfg = ctx, cfg
         H, W, n = cfg["H"], cfg["W"], cfg["n"]
         self.pipe = klt.Pipeline(ctx, W, H, n)
         self.fl = self.pipe.flist
-        self.ptrs = [ctx.device_upload(f) for f in frames]  # frames resident in HBM
+        self.frames = FrameStore(ctx, frames, host_frames)  # resident in HBM, or page-locked host
         self.seeds = seeds
         self.t = 0
         # pinned result ring: what the host (System::Track) reads each frame
         self.host = [ctx.pinned_array((3, n), np.float32) for _ in range(4)]
 
     def frame(self, t):
-        return (self.ptrs[t % len(self.ptrs)], self.cfg["W"])
+        return self.frames.frame(t)
 
     def start(self):
         self.pipe.upload_features(*self.seeds)
@@ -115,8 +190,7 @@ class Stream:
 
     def close(self):
         self.pipe.close()
-        for p in self.ptrs:
-            self.ctx.device_free(p)
+        self.frames.close()
         for _, p in self.host:
             self.ctx.pinned_free(p)
 
@@ -124,20 +198,20 @@ class Stream:
 class LookaheadStream:
     """The same stream through gklt_lookahead: batches of B frames per call."""
 
-    def __init__(self, ctx, cfg, frames, seeds, B):
+    def __init__(self, ctx, cfg, frames, seeds, B, host_frames=False):
         assert RESEED_EVERY % B == 0
         self.ctx, self.cfg, self.B = ctx, cfg, B
         H, W, n = cfg["H"], cfg["W"], cfg["n"]
         self.la = klt.Lookahead(ctx, W, H, n, B)
         self.fl = self.la.flist
-        self.ptrs = [ctx.device_upload(f) for f in frames]
+        self.frames = FrameStore(ctx, frames, host_frames)
         self.seeds = seeds
         self.t = 1           # next frame to submit
         self.pending = None  # first frame of the batch that the next submit will track
         self.host = [ctx.pinned_array((3, n), np.float32) for _ in range(4 * B)]
 
     def frame(self, t):
-        return (self.ptrs[t % len(self.ptrs)], self.cfg["W"])
+        return self.frames.frame(t)
 
     def start(self):
         self.la.upload_features(*self.seeds)
@@ -174,8 +248,7 @@ class LookaheadStream:
 
     def close(self):
         self.la.close()
-        for p in self.ptrs:
-            self.ctx.device_free(p)
+        self.frames.close()
         for _, p in self.host:
             self.ctx.pinned_free(p)
 
@@ -230,6 +303,34 @@ def latency_leg(st, n):
         lat.append((q1 - q0) * 1e3)
         full.append((time.perf_counter() - q0) * 1e3)
     return lat, full
+
+
+def pcie_legs(ctx, cfg, frames, seeds, B, steps, warmup):
+    """PCIe-inclusive rates (never `value`): frames start in page-locked HOST memory and are staged
+    H2D by the library inside the timed region; lists come back into pinned host memory.  Both
+    call patterns: gklt_pipeline_step (frame at a time) and gklt_lookahead_submit (B per call)."""
+    out = {}
+    legs = [("frame_at_a_time", 0)] + ([("lookahead", B)] if B else [])
+    for name, b in legs:
+        st = LookaheadStream(ctx, cfg, frames, seeds, b, host_frames=True) if b else \
+            Stream(ctx, cfg, frames, seeds, host_frames=True)
+        st.start()
+        st.run(warmup)
+        st.sync()
+        st.fl.stats(reset=True)
+        k = min(steps, 1024)
+        q0 = time.perf_counter()
+        st.run(k)
+        st.sync()
+        ctx.device_synchronize()
+        dt = time.perf_counter() - q0
+        tracked, _ = st.fl.stats(reset=True)
+        out[name] = {"value": tracked / dt, "ms_per_step": dt / k * 1e3, "steps": k,
+                     "h2d_GBps": k * cfg["H"] * cfg["W"] / dt / 1e9}
+        st.close()
+    out["mode"] = ("u8 frames in page-locked host memory, staged H2D by the library inside the timed "
+                   "region (img_on_device = 0); lists written to pinned host memory; rank 0")
+    return out
 
 
 def reduce_over_ranks(dist, dt, tracked, iters):
@@ -417,11 +518,191 @@ def main_multistream(a, ctx, cfg, gp, dist, rank, world):
         dist.destroy_process_group()
 
 
-def main():
-    a = parse()
+def c5_params(cfg):
+    sel = cfg["select"]
+    kw = dict(window=cfg["window"], levels=cfg["levels"], min_eigenvalue=sel["min_eigenvalue"],
+              mindist=sel["mindist"])
+    return kw, sel
+
+
+def cpu_baseline_c5(cfg, frames, nframes, threads, variant):
+    """C5 on the CPU restatement: pyramid, integral images, selection, track -- per frame."""
+    from oracle import oracle as ok
+
+    ok.build()
+    kw, sel = c5_params(cfg)
+    op = ok.make_params(**kw)
+    op.bordery = max(op.bordery, sel["min_bordery"])
+    ok.set_threads(threads)
+    n = cfg["n"]
+    cur = ok.compute_pyramid(op, frames[0])
+    t0 = time.perf_counter()
+    tracked = 0
+    for t in range(nframes):
+        nxt = ok.compute_pyramid(op, frames[(t + 1) % len(frames)])
+        sums = ok.integral_products(cur[1], cur[2])
+        x, y, val = ok.select_features(op, 0, variant, *sums, n, grid=sel["grid"])
+        val = ok.track_features(op, cur, nxt, x, y, val)[2]
+        tracked += int((val == 0).sum())
+        cur = nxt
+    dt = time.perf_counter() - t0
+    ok.set_threads(1)
+    return tracked / dt, dt
+
+
+def main_c5(a, ctx, cfg, dist, rank, world):
+    """--config C5 (BASELINE config 5): the selector runs on the current pyramid EVERY frame
+    (SELECT_ALL, Uniform flavour with 32x32-pixel cells by default), then the fresh list is tracked
+    to the next frame, whose pyramid was built meanwhile.  Everything stays on the device."""
+    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    sel = cfg["select"]
+    variant = {"uniform": klt.VARIANT_UNIFORM, "plain": klt.VARIANT_PLAIN, "round2": klt.VARIANT_ROUND2}[
+        a.select_variant]
+    frames = synth.make_stream(H, W, min(a.frames, 16), seed=rank_seed(rank))
+    store = FrameStore(ctx, frames)
+    ring = [klt.Pyramid(ctx, W, H) for _ in range(3)]
+    fl = klt.FeatureList(ctx, 100 * n)  # KLTCreateFeatureList's capacity (KLTUtil.cpp:53-55)
+    empty = (np.zeros(n, np.float32), np.zeros(n, np.float32), np.full(n, -1, np.int32))
+    fl.upload(*empty)
+    state = {"t": 0}
+
+    def run(k):
+        for t in range(state["t"], state["t"] + k):
+            cur, nxt = ring[t % 3], ring[(t + 1) % 3]
+            ptr, stride, _ = store.frame(t + 1)
+            nxt.build_from_device(ptr, stride)
+            klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, variant, fl, grid=sel["grid"])
+            klt.track_flist(ctx, cur, nxt, fl)
+        state["t"] += k
+
+    def barrier():
+        ctx.device_synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    ptr, stride, _ = store.frame(0)
+    ring[0].build_from_device(ptr, stride)
+    run(a.warmup)
+    ctx.sync()
+    fl.stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    run(a.steps)
+    ctx.sync()
+    ctx.device_synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    tracked, iters = fl.stats(reset=True)
+    nlist = len(fl)
+    dt_max, tracked_all, iters_all = reduce_over_ranks(dist, dt, tracked, iters)
+
+    psteps = min(a.steps, 64)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    run(psteps)
+    ctx.sync()
+    prof = ctx.profile_get()
+    ctx.profile_enable(False)
+    rounds = ctx.select_rounds()
+    p_tracked, p_iters = fl.stats(reset=True)
+
+    lat = []
+    for _ in range(min(a.steps, 64)):
+        q0 = time.perf_counter()
+        run(1)
+        ctx.sync()
+        lat.append((time.perf_counter() - q0) * 1e3)
+    lat = np.array(lat)
+
+    b_pyr, foot, px = algorithmic_bytes(cfg)
+    per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms, "us_per_frame": ms / psteps * 1e3}
+                  for k, (ms, cnt) in prof.items() if cnt}
+    # SURVEY 8(d), bytes per frame.  Selector (API form): three (H+1)(W+1) fp32 integral images read
+    # + the H x W featuremap read and written.  Integral producer: gx, gy read, three sums written.
+    alg_frame = {
+        "select": 3.0 * (W + 1) * (H + 1) * 4 + 2.0 * W * H,
+        "integral": 8.0 * W * H + 3.0 * (W + 1) * (H + 1) * 4,
+        "track": (4.0 * nlist * cfg["levels"] + 3.0 * p_iters / psteps) * foot,
+        "level0": W * H * (1 + 12 + 1.0),
+    }
+    dom = max((k for k in per_kernel if k in alg_frame), key=lambda k: per_kernel[k]["total_ms"])
+    achieved = alg_frame[dom] * psteps / (per_kernel[dom]["total_ms"] * 1e-3) / 1e9
+    names = {"track": "k_track_w", "level0": "k_level<u8>", "integral": "k_integral_rows/cols",
+             "select": "selector kernels (k_score, suppression rounds, rank/assign) of one selection"}
+    out = {
+        "metric": "tracked features*frames/sec at 1080p, 4000 pts, 4-level pyramid; per-frame latency",
+        "value": tracked_all / dt_max,
+        "unit": "tracked_features*frames/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": dt_max / a.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "C5: re-detection every frame on the synthetic %dx%d u8 stream: "
+                               "gklt_select_from_pyramid (SELECT_ALL, %s, gridSize %dx%d px, min_eigenvalue %d, "
+                               "mindist %d, %d features) on the current pyramid, then gklt_track_flist to the "
+                               "next frame (%d-level pyramid, %dx%d window), pyramid(t+1) built meanwhile; "
+                               "frames resident in HBM, one frame per call, 1 stream per GPU" % (
+                                   W, H, a.select_variant, sel["grid"][0], sel["grid"][1], sel["min_eigenvalue"],
+                                   sel["mindist"], n, cfg["levels"], cfg["window"], cfg["window"]),
+                   "frames_per_s": world * a.steps / dt_max,
+                   "list_size": nlist,
+                   "tracked_fraction": tracked_all / (world * a.steps * max(nlist, 1)),
+                   "newton_iters_per_feature_frame": iters_all / (world * a.steps * max(nlist, 1)),
+                   "suppression_launches_last_selection": {"phase_a": rounds[0], "phase_b": rounds[1]},
+                   "parallelism": "stream-sharded x%d, no collective" % world},
+        "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                       "mode": "build(t+1) + select(t) + track(t -> t+1) enqueued -> both streams drained"},
+        "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_frame[dom] * psteps / per_kernel[dom]["launches"],
+                     "algorithmic_bytes_per_frame": alg_frame[dom],
+                     "avg_launch_us": per_kernel[dom]["avg_us"],
+                     "frames_in_profiled_launches": psteps, "profiled_launches": per_kernel[dom]["launches"],
+                     "note": "dominant kernel group by total time in the profiled leg; achieved = bytes per "
+                             "frame (SURVEY 8d) x frames / total time of that group's launches"},
+        "kernels": per_kernel,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu:
+        threads = min(16, len(os.sched_getaffinity(0)))
+        ncpu = a.cpu_frames or 24
+        v, cdt = cpu_baseline_c5(cfg, frames, ncpu, threads, variant)
+        out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads, "kind": "port",
+                               "sample": "%d frames of the same stream (pyramid + integral images + selection + "
+                                         "track), oracle/ C restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
+    for p in ring:
+        p.close()
+    fl.close()
+    store.close()
+    ctx.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if "RANK" not in os.environ and a.gpus > 1:
+        return launch_ranks(a, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: start it with --gpus equal to the "
+                         "number of ranks" % (a.gpus, world))
+    device = 0 if a.share_gpu else local_rank
+    if a.dry_launch:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "device": device,
+                          "streams": shard_streams(a.streams, world, rank) if a.streams else None}), flush=True)
+        return 0
+    klt.lib()  # libgklt.so and the system HIP runtime, before torch can be imported
 
     dist = None
     if world > 1:
@@ -432,10 +713,16 @@ def main():
     cfg = dict(synth.CONFIGS[a.config])
     H, W, n = cfg["H"], cfg["W"], cfg["n"]
     params_kw = dict(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
+    if "select" in cfg:
+        params_kw = c5_params(cfg)[0]
     gp = klt.make_params(**params_kw)
-    ctx = klt.Context(0 if a.share_gpu else local_rank, gp)
+    if "select" in cfg:
+        gp.bordery = max(gp.bordery, cfg["select"]["min_bordery"])
+    ctx = klt.Context(device, gp)
     ctx.set_track_waves(a.track_waves)
     ctx.set_track_impl(a.track_impl)
+    if "select" in cfg and not a.streams:
+        return main_c5(a, ctx, cfg, dist, rank, world)
     if a.streams > 0:
         return main_multistream(a, ctx, cfg, gp, dist, rank, world)
 
@@ -470,6 +757,9 @@ def main():
         fa1 = (tracked1, dt1, k1)
         lat, lat_full = latency_leg(st1, min(a.steps, 256))
         st1.close()
+    pcie = None
+    if rank == 0 and not a.main_only and not a.no_pcie:
+        pcie = pcie_legs(ctx, cfg, frames, seeds, B, a.steps, a.warmup)
 
     if B:
         st = LookaheadStream(ctx, cfg, frames, seeds, B)
@@ -490,8 +780,13 @@ def main():
     tracked, iters = st.fl.stats(reset=True)
     dt_max, tracked_all, iters_all = reduce_over_ranks(dist, dt, tracked, iters)
 
-    # ---- roofline leg: the same steps, every launch bracketed by HIP events on its own stream
+    # ---- roofline leg: the same steps, every launch bracketed by HIP events on its own stream.
+    # Whole batches only (the leg starts with nothing pending: st.sync() above tracked the last
+    # batch), so every profiled launch of a kernel carries the same number of frames and
+    # achieved = sum of bytes / sum of kernel time.
     psteps = min(a.steps, 512)
+    if B:
+        psteps = max(B, psteps // B * B)
     ctx.profile_enable(True)
     ctx.profile_reset()
     st.run(psteps)
@@ -528,20 +823,23 @@ def main():
     b_pyr, foot, px = algorithmic_bytes(cfg)
     per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}
                   for k, (ms, cnt) in prof.items() if cnt}
-    fpl = max(B, 1)  # frames per launch
-    # Algorithmic bytes per launch.  Tracker: n features x L levels x (3 template
-    # planes + 1 residue plane) + 3 planes per Newton iteration, each plane one (w+1)(h+1) fp32
-    # bilinear footprint.  Level-0 kernel: u8 in, (I, gx, gy) out, decimated plane out.
-    alg_by_kernel = {
-        "track": (4.0 * n * cfg["levels"] * fpl + 3.0 * p_iters / psteps * fpl) * foot,
-        "level0": fpl * W * H * (1 + 12 + 1.0),
+    # Algorithmic bytes of the profiled leg = bytes per frame x the psteps frames its
+    # launches processed.  Tracker: n features x L levels x (3 template planes + 1 residue plane)
+    # + 3 planes per Newton iteration, each plane one (w+1)(h+1) fp32 bilinear footprint.  Level-0
+    # kernel: u8 in, (I, gx, gy) out, decimated plane out.
+    alg_leg = {
+        "track": (4.0 * n * cfg["levels"] * psteps + 3.0 * p_iters) * foot,
+        "level0": float(psteps) * W * H * (1 + 12 + 1.0),
     }
-    dom = max((k for k in per_kernel if k in alg_by_kernel), key=lambda k: per_kernel[k]["total_ms"])
-    avg_s = per_kernel[dom]["avg_us"] * 1e-6
-    alg = alg_by_kernel[dom]
-    achieved = alg / avg_s / 1e9
-    # HBM bytes per frame from the rocprofv3 PMC passes committed under profiles/ (see PMC_TRAFFIC)
-    pmc_traffic = PMC_TRAFFIC.get((a.config, dom))
+    dom = max((k for k in per_kernel if k in alg_leg), key=lambda k: per_kernel[k]["total_ms"])
+    launches = per_kernel[dom]["launches"]
+    fpl = psteps / launches                       # frames per launch (whole batches: an integer)
+    alg = alg_leg[dom] / launches                 # algorithmic bytes per launch
+    achieved = alg_leg[dom] / (per_kernel[dom]["total_ms"] * 1e-3) / 1e9
+    alg_by_kernel = {k: v / psteps * max(B, 1) for k, v in alg_leg.items()}  # per full batch
+    # HBM bytes per frame from the rocprofv3 PMC passes committed under profiles/ (an OFFLINE
+    # constant, not collected by this run): only quoted for the configuration it was collected on
+    pmc_traffic = PMC_TRAFFIC.get((a.config, dom)) if fpl == 16 else None
 
     names = {"track": "k_track_w", "level0": "k_level<u8>"}
     out = {
@@ -558,8 +856,13 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s: synthetic %dx%d u8 stream, %d features, %d-level pyramid, %dx%d window, "
-                               "1 independent stream per GPU" % (a.config, W, H, n, cfg["levels"],
-                                                                 cfg["window"], cfg["window"]),
+                               "1 independent stream per GPU; frames RESIDENT IN HBM before the timed "
+                               "region, handed over %s; the drop-in call pattern (one frame per call, "
+                               "preload depth 1) is `frame_at_a_time`, host-resident frames are "
+                               "`pcie_inclusive`" % (
+                                   a.config, W, H, n, cfg["levels"], cfg["window"], cfg["window"],
+                                   ("%d frames per gklt_lookahead_submit call" % B) if B else
+                                   "one frame per gklt_pipeline_step call"),
                    "frames_per_s": world * a.steps / dt_max,
                    "tracked_fraction": tracked_all / (world * a.steps * n),
                    "newton_iters_per_feature_frame": iters_all / (world * a.steps * n),
@@ -579,7 +882,8 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic * fpl if pmc_traffic else None,
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": per_kernel[dom]["avg_us"],
-                     "frames_per_launch": fpl,
+                     "frames_per_launch": fpl, "frames_in_profiled_launches": psteps,
+                     "profiled_launches": launches,
                      "level0_alone": ({"avg_launch_us": alone["level0"],
                                        "achieved": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9,
                                        "frac": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -588,9 +892,12 @@ def main():
                      "note": "dominant kernel by total time in the profiled leg; tracker bytes = "
                              "[4*N*L + 3*iters] footprints of (w+1)(h+1)*4 B per frame "
                              "(iters/feature/frame=%.2f), level-0 bytes = W*H*(1+12+1) per frame; "
-                             "traffic = (2*FETCH_SIZE + WRITE_SIZE) per frame from the rocprofv3 --pmc passes "
-                             "in profiles/r01_c2_lookahead16_pmc_by_kernel.txt (16-frame launches) x "
-                             "frames_per_launch; see DESIGN.md 4" % (p_iters / psteps / n)},
+                             "achieved = bytes of the frames_in_profiled_launches frames / total kernel time "
+                             "of the profiled launches (HIP events on the kernel's own stream); "
+                             "traffic = offline constant: (2*FETCH_SIZE + WRITE_SIZE) per frame from the "
+                             "rocprofv3 --pmc passes in profiles/ (16-frame launches) x frames_per_launch, "
+                             "null for other launch sizes; see DESIGN.md 4" % (p_iters / psteps / n)},
+        "pcie_inclusive": pcie,
         "kernels": per_kernel,
         "pyramid_algorithmic_bytes_per_frame": b_pyr,
     }
@@ -614,4 +921,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

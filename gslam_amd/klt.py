@@ -364,8 +364,11 @@ class Pipeline:
         if isinstance(img, np.ndarray):
             img = np.ascontiguousarray(img, np.uint8)
             return img, img.ctypes.data_as(C.POINTER(C.c_uint8)), img.strides[0], 0
-        ptr, stride = img  # (device pointer, stride)
-        return None, C.cast(C.c_void_p(ptr), C.POINTER(C.c_uint8)), stride, 1
+        # (pointer, stride[, on_device = 1]): a device frame, or with on_device = 0 a page-locked
+        # host frame that the caller keeps alive until the step's staging copy has run
+        ptr, stride = img[0], img[1]
+        dev = int(img[2]) if len(img) > 2 else 1
+        return None, C.cast(C.c_void_p(ptr), C.POINTER(C.c_uint8)), stride, dev
 
     def start(self, img0, img1):
         k0, p0, s0, d0 = self._img(img0)
@@ -529,7 +532,7 @@ class MultiStream:
             return
         keep, arr, stride, dev = self._imgs(imgs_next)
         _check(lib().gklt_multistream_step(self.h, arr, stride, dev, C.c_void_p(host_out)))
-        if not dev:
+        if keep[0][0] is not None:
             self.sync()  # pageable host frames must stay alive until staged
 
     def upload_features(self, stream, x, y, val):

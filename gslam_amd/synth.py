@@ -73,4 +73,8 @@ CONFIGS = {
     "C2": dict(H=1080, W=1920, levels=4, window=7, n=4000, lattice=(80, 50)),
     "C3": dict(H=2160, W=3840, levels=5, window=11, n=16000, lattice=(160, 100)),
     "Cship": dict(H=1080, W=1920, levels=2, window=21, n=2000, lattice=(60, 34), border=50),
+    # re-detection every frame: Uniform selector with gridSize (32, 32), bordery >= 24
+    # (SURVEY A.3 hazard 1), then track
+    "C5": dict(H=1080, W=1920, levels=4, window=7, n=4000, lattice=(80, 50),
+               select=dict(min_eigenvalue=100, mindist=10, grid=(32, 32), min_bordery=24)),
 }

@@ -45,3 +45,34 @@ def test_two_rank_reduction_and_sharding(tmp_path):
     assert res[0]["seed"] != res[1]["seed"]   # independent streams per rank
     # config 4: stream s -> rank s mod world; every stream on exactly one rank
     assert res[0]["streams"] == [0, 2, 4, 6] and res[1]["streams"] == [1, 3, 5]
+
+
+def _bench(*args, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=e,
+                          capture_output=True, text=True, timeout=120)
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`bench.py --gpus N` outside torch.distributed.run starts N ranks itself (no HIP call in the
+    launcher): every rank sees its own RANK / LOCAL_RANK -> device and the config-4 partition."""
+    import json
+    r = _bench("--gpus", "4", "--streams", "64", "--dry-launch")
+    assert r.returncode == 0, r.stderr
+    ranks = [json.loads(l) for l in r.stdout.splitlines()]
+    assert [d["rank"] for d in ranks] == [0, 1, 2, 3]
+    assert all(d["world"] == 4 and d["device"] == d["local_rank"] == d["rank"] for d in ranks)
+    assert sorted(s for d in ranks for s in d["streams"]) == list(range(64))
+    assert all(len(d["streams"]) == 16 for d in ranks)
+    # rehearsal on a 1-GPU box: every rank on device 0
+    r = _bench("--gpus", "2", "--share-gpu", "--dry-launch")
+    assert [json.loads(l)["device"] for l in r.stdout.splitlines()] == [0, 0]
+
+
+def test_bench_rejects_gpus_that_disagree_with_world_size():
+    r = _bench("--gpus", "8", "--dry-launch", env=dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # bad arguments fail in the launcher, before any rank starts
+    r = _bench("--gpus", "2", "--dry-launch", "--config", "nope")
+    assert r.returncode != 0
