@@ -69,6 +69,36 @@ def build(force=False, verbose=False, extra=()):
     return LIB
 
 
+ROOT = os.path.dirname(HERE)
+SHIM_SRC = [os.path.join(ROOT, "shim", "gklt_shim.cpp"), os.path.join(ROOT, "tests", "shim_mock", "shim_driver.cpp")]
+SHIM_TEST_LIB = os.path.join(ROOT, "tests", "shim_mock", "libgklt_shimtest.so")
+
+
+def shim_deps():
+    deps = list(SHIM_SRC) + [os.path.join(ROOT, "include", "gklt.h"), LIB]
+    for d in (os.path.join(ROOT, "shim"), os.path.join(ROOT, "tests", "shim_mock")):
+        for dirpath, _, files in os.walk(d):
+            deps += [os.path.join(dirpath, f) for f in files if not f.endswith(".so")]
+    return deps
+
+
+def build_shim_test(force=False, verbose=False):
+    """shim/gklt_shim.cpp (GSLAM's C++ host API over the C ABI) + the test driver, compiled with g++
+    against the cv::Mat / Eigen stand-ins of tests/shim_mock/ and linked to libgklt.so.  Host code
+    only: proves that the shim compiles against include/gklt.h and lets tests/test_shim.py run it."""
+    if not force and not _newer(SHIM_TEST_LIB, shim_deps()):
+        return SHIM_TEST_LIB
+    cmd = ["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-Werror", "-Wno-write-strings",
+           "-I" + os.path.join(ROOT, "tests", "shim_mock"), "-I" + os.path.join(ROOT, "shim"),
+           "-I" + os.path.join(ROOT, "include")] + SHIM_SRC + [
+           "-o", SHIM_TEST_LIB, "-L" + HERE, "-lgklt", "-Wl,-rpath,$ORIGIN/../../gslam_amd", "-Wl,--no-undefined", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return SHIM_TEST_LIB
+
+
 if __name__ == "__main__":
     build(force="-f" in sys.argv, verbose=True)
+    build_shim_test(force="-f" in sys.argv, verbose=True)
     print(LIB)

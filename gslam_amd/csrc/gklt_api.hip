@@ -123,11 +123,21 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   gklt_ctx *c = new gklt_ctx();
   c->device = device;
   gklt_default_params(&c->prm);
-  GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
-  GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
-  GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
-  // this device's copy of the allocation-free entry point's scratch array
-  GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
+  const int rc = [&]() -> int {
+    GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
+    GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+    GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
+    // this device's copy of the allocation-free entry point's scratch array
+    GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
+    return 0;
+  }();
+  if (rc) {  // release what the failed set-up had created (gklt_last_error keeps its message)
+    if (c->s_pyr) (void)hipStreamDestroy(c->s_pyr);
+    if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
+    if (c->d_invk) (void)hipFree(c->d_invk);
+    delete c;
+    return rc;
+  }
   *out = c;
   return 0;
 }
@@ -208,8 +218,12 @@ extern "C" int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_py
     gklt_pyramid_destroy(py);
     return GKLT_ENOMEM;
   }
-  GKLT_HIP(hipEventCreateWithFlags(&py->ready, hipEventDisableTiming));
-  GKLT_HIP(hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming));
+  if (hipEventCreateWithFlags(&py->ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming) != hipSuccess) {
+    set_error("hipEventCreate for a pyramid failed");
+    gklt_pyramid_destroy(py);
+    return GKLT_EHIP;
+  }
   *out = py;
   return 0;
 }
@@ -530,7 +544,16 @@ extern "C" int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out) 
   }
   fl->y = fl->x + capacity;
   fl->val = reinterpret_cast<int *>(fl->x + 2 * (size_t)capacity);
-  GKLT_HIP(hipMemsetAsync(fl->stats, 0, 2 * GKLT_STAT_SHARDS * sizeof(unsigned long long), ctx->s_trk));
+  // Entries beyond the list's size are defined: x = y = 0, val = -1 (0xFF bytes = KLT_NOT_FOUND), so
+  // whole-capacity downloads (gklt_flist_download_packed_async, pageable host_out) never carry
+  // uninitialised device memory.
+  if (hipMemsetAsync(fl->stats, 0, 2 * GKLT_STAT_SHARDS * sizeof(unsigned long long), ctx->s_trk) != hipSuccess ||
+      hipMemsetAsync(fl->x, 0, 2 * sizeof(float) * (size_t)capacity, ctx->s_trk) != hipSuccess ||
+      hipMemsetAsync(fl->val, 0xFF, sizeof(int) * (size_t)capacity, ctx->s_trk) != hipSuccess) {
+    set_error("hipMemsetAsync of a new feature list failed");
+    gklt_flist_destroy(fl);
+    return GKLT_EHIP;
+  }
   *out = fl;
   return 0;
 }
@@ -538,10 +561,43 @@ extern "C" int gklt_flist_create(gklt_ctx *ctx, int capacity, gklt_flist **out) 
 extern "C" int gklt_flist_destroy(gklt_flist *fl) {
   if (!fl) return 0;
   (void)hipSetDevice(fl->ctx->device);
-  (void)hipStreamSynchronize(fl->ctx->s_trk);
+  (void)hipDeviceSynchronize();  // staged uploads may be queued on a pipeline's stream
   (void)hipFree(fl->x);
   (void)hipFree(fl->stats);
+  if (fl->h_stage) (void)hipHostFree(fl->h_stage);
+  if (fl->stage_done) (void)hipEventDestroy(fl->stage_done);
   delete fl;
+  return 0;
+}
+
+int gklt::flist_upload_staged(gklt_flist *fl, hipStream_t s, size_t off, int n, const float *x,
+                              const float *y, const int *val) {
+  if (n <= 0) return 0;
+  const size_t cap = (size_t)fl->capacity;
+  if (!fl->h_stage) {
+    GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&fl->h_stage), 3 * sizeof(float) * cap, hipHostMallocDefault));
+    GKLT_HIP(hipEventCreateWithFlags(&fl->stage_done, hipEventDisableTiming));
+  }
+  // the mirror has the list's layout, so uploads of disjoint segments (the streams of a
+  // gklt_multistream) never wait for each other; a segment is rewritten only after the copies
+  // that read it have finished
+  const size_t a = off, b = off + (size_t)n;
+  bool wait = fl->stage_pending.size() >= 256;
+  for (auto &seg : fl->stage_pending) wait = wait || (a < seg.second && seg.first < b);
+  if (wait) {
+    GKLT_HIP(hipEventSynchronize(fl->stage_done));
+    fl->stage_pending.clear();
+  }
+  float *hx = fl->h_stage + off, *hy = fl->h_stage + cap + off;
+  int *hv = reinterpret_cast<int *>(fl->h_stage + 2 * cap) + off;
+  std::memcpy(hx, x, sizeof(float) * n);
+  std::memcpy(hy, y, sizeof(float) * n);
+  std::memcpy(hv, val, sizeof(int) * n);
+  GKLT_HIP(hipMemcpyAsync(fl->x + off, hx, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  GKLT_HIP(hipMemcpyAsync(fl->y + off, hy, sizeof(float) * n, hipMemcpyHostToDevice, s));
+  GKLT_HIP(hipMemcpyAsync(fl->val + off, hv, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  GKLT_HIP(hipEventRecord(fl->stage_done, s));
+  fl->stage_pending.emplace_back(a, b);
   return 0;
 }
 
@@ -555,12 +611,7 @@ extern "C" int gklt_flist_upload(gklt_ctx *ctx, gklt_flist *fl, int n, const flo
     return GKLT_ECAPACITY;
   }
   if (int rc = use_device(ctx)) return rc;
-  hipStream_t s = ctx->s_trk;
-  if (n > 0) {
-    GKLT_HIP(hipMemcpyAsync(fl->x, x, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    GKLT_HIP(hipMemcpyAsync(fl->y, y, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    GKLT_HIP(hipMemcpyAsync(fl->val, val, sizeof(int) * n, hipMemcpyHostToDevice, s));
-  }
+  if (int rc = flist_upload_staged(fl, ctx->s_trk, 0, n, x, y, val)) return rc;
   fl->n = n;
   return 0;
 }

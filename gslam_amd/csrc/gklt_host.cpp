@@ -157,6 +157,14 @@ extern "C" int gklt_default_params(gklt_params *p) {  // KLTUtil.cpp:12-46,298-3
   return gklt_update_tc_border(p);
 }
 
+extern "C" int gklt_feature_list_capacity(int nFeatures) {  // KLTUtil.cpp:53-55,68
+  if (nFeatures < 0 || nFeatures > 0x7fffffff / 100) {
+    set_error("KLTCreateFeatureList: %d features", nFeatures);
+    return GKLT_EINVAL;
+  }
+  return 100 * nFeatures;
+}
+
 extern "C" int gklt_count_remaining(int n, const int *val) {  // LK.hpp:27-38
   int c = 0;
   for (int i = 0; i < n; ++i) c += val[i] >= 0;

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gklt.h"
@@ -103,6 +104,10 @@ struct gklt_flist {
   float *x = nullptr, *y = nullptr;
   int *val = nullptr;
   unsigned long long *stats = nullptr;  // GKLT_STAT_SHARDS x {tracked, iterations}
+  // page-locked mirror of the list layout through which host lists are uploaded (flist_upload_staged)
+  float *h_stage = nullptr;
+  hipEvent_t stage_done = nullptr;
+  std::vector<std::pair<size_t, size_t>> stage_pending;  // [first, last) entries still being copied
 };
 
 namespace gklt {
@@ -156,6 +161,11 @@ int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, 
                          int slot1, int slot2, int cap, const int *n, const gklt_pyramid *py0,
                          float *x, float *y, int *val, unsigned long long *stats, float *mirror,
                          int mirror_stride);
+// Replaces entries [off, off + n) of the list from host arrays on stream s.  The arrays may be
+// pageable and may be reused as soon as the call returns: they are copied into the list's
+// page-locked mirror first, and the H2D copies read from there (gklt_api.hip).
+int flist_upload_staged(gklt_flist *fl, hipStream_t s, size_t off, int n, const float *x,
+                        const float *y, const int *val);
 // bearing vectors (gklt_bearing.hip); grows ctx->d_norm / d_vec to n entries (gklt_api.hip)
 int ensure_bearing_buffers(gklt_ctx *ctx, int n);
 // all launches of one pyramid build on stream s (gklt_api.hip)

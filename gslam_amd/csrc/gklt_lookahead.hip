@@ -233,11 +233,7 @@ extern "C" int gklt_lookahead_upload_features(gklt_lookahead *p, int n, const fl
   }
   GKLT_HIP(hipSetDevice(p->ctx->device));
   // stream T: after the last tracker launch, before the next one
-  if (n > 0) {
-    GKLT_HIP(hipMemcpyAsync(p->fl->x, x, sizeof(float) * n, hipMemcpyHostToDevice, p->st));
-    GKLT_HIP(hipMemcpyAsync(p->fl->y, y, sizeof(float) * n, hipMemcpyHostToDevice, p->st));
-    GKLT_HIP(hipMemcpyAsync(p->fl->val, val, sizeof(int) * n, hipMemcpyHostToDevice, p->st));
-  }
+  if (int rc = flist_upload_staged(p->fl, p->st, 0, n, x, y, val)) return rc;
   p->fl->n = n;
   return 0;
 }

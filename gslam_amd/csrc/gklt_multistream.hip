@@ -234,11 +234,7 @@ extern "C" int gklt_multistream_upload_features(gklt_multistream *m, int stream,
   GKLT_HIP(hipSetDevice(m->ctx->device));
   // stream T: after the last tracker launch, before the next one
   const size_t o = (size_t)stream * m->cap;
-  if (n > 0) {
-    GKLT_HIP(hipMemcpyAsync(m->fl->x + o, x, sizeof(float) * n, hipMemcpyHostToDevice, m->st));
-    GKLT_HIP(hipMemcpyAsync(m->fl->y + o, y, sizeof(float) * n, hipMemcpyHostToDevice, m->st));
-    GKLT_HIP(hipMemcpyAsync(m->fl->val + o, val, sizeof(int) * n, hipMemcpyHostToDevice, m->st));
-  }
+  if (int rc = flist_upload_staged(m->fl, m->st, o, n, x, y, val)) return rc;
   m->n[stream] = n;
   return 0;
 }

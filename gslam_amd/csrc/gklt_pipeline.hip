@@ -195,11 +195,7 @@ extern "C" int gklt_pipeline_upload_features(gklt_pipeline *p, int n, const floa
   const int si = (int)(p->t & 1), so = si ^ 1;
   hipStream_t s = p->st[si];
   if (p->started && p->has_trk[so]) GKLT_HIP(hipStreamWaitEvent(s, p->e_trk[so], 0));
-  if (n > 0) {
-    GKLT_HIP(hipMemcpyAsync(p->fl->x, x, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    GKLT_HIP(hipMemcpyAsync(p->fl->y, y, sizeof(float) * n, hipMemcpyHostToDevice, s));
-    GKLT_HIP(hipMemcpyAsync(p->fl->val, val, sizeof(int) * n, hipMemcpyHostToDevice, s));
-  }
+  if (int rc = flist_upload_staged(p->fl, s, 0, n, x, y, val)) return rc;
   p->fl->n = n;
   return 0;
 }

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgklt.so")
+LIB_PATH = os.environ.get("GKLT_LIB") or os.path.join(_HERE, "libgklt.so")  # GKLT_LIB: A/B builds
 
 KLT_TRACKED, KLT_NOT_FOUND, KLT_SMALL_DET = 0, -1, -2
 KLT_MAX_ITERATIONS, KLT_OOB, KLT_LARGE_RESIDUE = -3, -4, -5

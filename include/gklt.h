@@ -84,6 +84,12 @@ int gklt_compute_kernels(float sigma, float *gauss, int *gauss_width, float *der
 float gklt_compute_smooth_sigma(const gklt_params *p);
 /* KLTCountRemainingFeatures (LK.hpp:27-38). */
 int gklt_count_remaining(int n, const int *val);
+/* KLTCreateFeatureList (KLTUtil.cpp:49-83) allocates 100 x nFeatures records so that
+ * KLTSelectGoodFeaturesUniform can grow the list (selectGoodFeatures.hpp:1257): the number of
+ * entries a host SoA list, a gklt_flist or gklt_select's `capacity` needs for a list created with
+ * nFeatures.  The AoS list itself (KLT_FeatureRec holds cv::Mat / Eigen members) is built by the
+ * C++ shim (shim/gklt_shim.cpp) with this capacity.  Negative nFeatures: GKLT_EINVAL. */
+int gklt_feature_list_capacity(int nFeatures);
 
 /* ---- context ---- */
 
@@ -234,7 +240,10 @@ int gklt_pipeline_start(gklt_pipeline *p, const uint8_t *img0, const uint8_t *im
  * frame (img_on_device = 0) must stay valid until the step's staging copy has run. */
 int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int stride, int img_on_device,
                        void *host_out);
-/* Replaces the tracked list (keyframe re-seeding, System.cpp:415-420); ordered with the steps. */
+/* Replaces the tracked list (keyframe re-seeding, System.cpp:415-420); ordered with the steps.
+ * x / y / val may be pageable and may be reused as soon as the call returns (they are copied
+ * into a page-locked mirror of the list first); the same holds for gklt_flist_upload,
+ * gklt_lookahead_upload_features and gklt_multistream_upload_features. */
 int gklt_pipeline_upload_features(gklt_pipeline *p, int n, const float *x, const float *y,
                                   const int *val);
 int gklt_pipeline_sync(gklt_pipeline *p);

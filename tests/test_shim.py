@@ -1,0 +1,170 @@
+"""shim/gklt_shim.cpp -- GSLAM's C++ host API (KLTUtil.h, pyramid.h, convolve.h, LK.hpp,
+selectGoodFeatures.hpp signatures) on top of the C ABI -- compiled against the cv::Mat / Eigen
+stand-ins of tests/shim_mock/ and RUN: host-only entry points here, the GPU entry points on the
+GPU box against the oracle.  A signature drift between include/gklt.h and the shim fails the build
+(-Wall -Werror -Wl,--no-undefined)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def drv(klt):
+    from gslam_amd import build as b
+
+    path = b.SHIM_TEST_LIB
+    if not os.path.exists(path):  # built by __graft_entry__.build(); rebuilt on demand where g++ is at hand
+        b.build_shim_test()
+    return C.CDLL(path)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def test_shim_sources_name_every_reference_entry_point():
+    """KLTUtil.h:12-16, pyramid.h:11, convolve.h:12-13, LK.hpp:27,972, selectGoodFeatures.hpp:424-1341
+    plus the two header-less functions of KLTUtil.cpp (:87, :225)."""
+    src = open(os.path.join(ROOT, "shim", "gklt_shim.cpp")).read()
+    for name in ["KLTCreateTrackingContext()", "KLTCreateFeatureList(", "computeKernels(", "_KLTComputeSmoothSigma(",
+                 "KLTChangeTCPyramid(", "KLTUpdateTCBorder(", "computePyramid(", "computeGradients(",
+                 "computeSmoothedImage(", "KLTTrackFeatures(", "KLTCountRemainingFeatures(",
+                 "KLTSelectGoodFeatures(", "KLTReplaceLostFeatures(", "KLTSelectGoodFeatures2(",
+                 "KLTReplaceLostFeatures2(", "KLTSelectGoodFeaturesUniform(", "KLTReplaceLostFeaturesUniform("]:
+        assert ("\n" + name) in src.replace("void ", "\n").replace("int ", "\n").replace("float ", "\n") \
+            .replace("KLT_TrackingContext ", "\n").replace("KLT_FeatureList ", "\n"), name
+
+
+def test_shim_tracking_context_defaults(drv, ok):
+    iv = np.zeros(16, np.int32)
+    fv = np.zeros(11, np.float32)
+    drv.drv_defaults(_ip(iv), _fp(fv))
+    p = ok.default_params()
+    assert list(iv[:10]) == [p.mindist, p.window_width, p.window_height, p.min_eigenvalue, p.max_iterations,
+                             p.nSkippedPixels, p.borderx, p.bordery, p.nPyramidLevels, p.subsampling]
+    assert list(iv[:10]) == [10, 21, 21, 200, 10, 0, 32, 32, 2, 2]
+    assert list(iv[10:]) == [-1, 15, 10, 0, 1, 0]                           # KLTUtil.cpp:32-44
+    want = np.array([p.min_determinant, p.min_displacement, p.max_residue, p.grad_sigma, p.smooth_sigma_fact,
+                     p.pyramid_sigma_fact, p.step_factor, 10.0, 0.02, 1.5, np.float32(0.1) * np.float32(21)], np.float32)
+    assert (fv == want).all()
+
+
+@pytest.mark.parametrize("ww,wh,sr", [(21, 21, 15), (7, 7, 15), (6, 2, 15), (11, 11, 40), (3, 3, 100), (31, 31, 10)])
+def test_shim_change_pyramid_and_border(drv, ok, ww, wh, sr):
+    out = np.zeros(6, np.int32)
+    w0 = drv.drv_warnings()
+    drv.drv_pyramid_and_border(ww, wh, sr, _ip(out))
+    p = ok.default_params()
+    p.window_width, p.window_height = ww, wh
+    ok.change_tc_pyramid(p, sr)
+    ok.update_border(p)
+    assert list(out) == [p.window_width, p.window_height, p.nPyramidLevels, p.subsampling, p.borderx, p.bordery]
+    # even / too small windows are corrected with a KLTWarning (KLTUtil.cpp:94-113)
+    assert (drv.drv_warnings() > w0) == (ww % 2 == 0 or wh % 2 == 0 or ww < 3 or wh < 3)
+
+
+def test_shim_compute_kernels(drv, ok):
+    for sigma in (0.7, 1.0, 1.8, 2.1):
+        g, d = np.zeros(71, np.float32), np.zeros(71, np.float32)
+        gw, dw = C.c_int(), C.c_int()
+        drv.drv_kernels(C.c_float(sigma), _fp(g), C.byref(gw), _fp(d), C.byref(dw))
+        rg, rd = ok.compute_kernels(sigma)
+        assert gw.value == len(rg) and dw.value == len(rd)
+        assert (g[: gw.value] == rg).all() and (d[: dw.value] == rd).all()
+
+
+def test_shim_feature_list_layout(drv):
+    """KLTCreateFeatureList: one block, 100 n records, aff_* initialised (KLTUtil.cpp:49-83)."""
+    out = (C.c_long * 6)()
+    drv.drv_feature_list(37, out)
+    assert out[0] == 37 and out[1] == 1 and out[2] == 1 and out[3] == 1 and out[4] == 1
+    assert out[5] == sum(1 for i in range(37) if i % 3)     # KLTCountRemainingFeatures
+
+
+# ------------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+def test_shim_compute_pyramid_and_track_match_oracle(drv, ok):
+    from gslam_amd import synth
+
+    H, W, n, win, L = 270, 480, 600, 7, 3
+    T = synth.base_texture(H, W, seed=11)
+    f0, f1 = synth.render_frame(T, H, W, 0, seed=11), synth.render_frame(T, H, W, 1, seed=11)
+    op = ok.make_params(window=win, levels=L)
+    x, y = synth.lattice_seeds(H, W, n, op.borderx)
+    val = np.zeros(n, np.int32)
+    val[::17] = -3                               # dead features stay untouched
+    invK = np.linalg.inv(np.array([[400.0, 0, W / 2], [0, 400.0, H / 2], [0, 0, 1]]))
+    gx, gy, gv = x.copy(), y.copy(), val.copy()
+    norm, vec = np.zeros((n, 3)), np.zeros((n, 3))
+    wl, hl = W >> (L - 1), H >> (L - 1)
+    coarse = np.zeros((hl, wl), np.float32)
+    wh = np.zeros(2, np.int32)
+    dp = C.POINTER(C.c_double)
+    rc = drv.drv_track(W, H, W, f0.ctypes.data_as(C.POINTER(C.c_uint8)), f1.ctypes.data_as(C.POINTER(C.c_uint8)),
+                       win, L, -1, n, _fp(gx), _fp(gy), _ip(gv), invK.ctypes.data_as(dp), norm.ctypes.data_as(dp),
+                       vec.ctypes.data_as(dp), _fp(coarse), _ip(wh))
+    assert rc == 0
+    r0, r1 = ok.compute_pyramid(op, f0), ok.compute_pyramid(op, f1)
+    rx, ry, rv, rn, rvec = ok.track_features(op, r0, r1, x, y, val, invK=invK)
+    assert (gv == rv).all() and (gx == rx).all() and (gy == ry).all()
+    t = rv == 0
+    assert t.sum() > 0.8 * n
+    assert np.abs(norm[t] - rn[t]).max() <= 1e-15 and np.abs(vec[t] - rvec[t]).max() <= 1e-15
+    # the plane System reads on the host (System.cpp:407,672): pyramid[3 * (L - 1)]
+    assert list(wh) == [wl, hl]
+    assert (coarse.view(np.uint32) == r1[3 * (L - 1)].view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,mode,variant", [(0, 0, 0), (1, 1, 0), (2, 0, 1), (3, 1, 1), (4, 0, 2), (5, 1, 2)])
+def test_shim_selectors_match_oracle(drv, ok, which, mode, variant):
+    from gslam_amd import synth
+
+    H, W, n, win, L = 200, 320, 150, 7, 2
+    T = synth.base_texture(H, W, seed=3)
+    f0 = synth.render_frame(T, H, W, 0, seed=3)
+    op = ok.make_params(window=win, levels=L, min_eigenvalue=60, mindist=8)
+    pyr = ok.compute_pyramid(op, f0)
+    sums = ok.integral_products(pyr[1], pyr[2])
+    cap = 100 * n
+    x, y, v = np.full(cap, -1, np.float32), np.full(cap, -1, np.float32), np.full(cap, -1, np.int32)
+    if mode == 1:  # a list with survivors and lost entries
+        sx, sy = synth.lattice_seeds(H, W, n, op.borderx + 3, seed=9)
+        x[:n], y[:n] = np.round(sx), np.round(sy)
+        v[:n] = np.where(np.arange(n) % 3 == 0, -2, 0)
+    ex, ey, ev = ok.select_features(op, mode, variant, *sums, n, x=x[:n] if mode else None, y=y[:n] if mode else None,
+                                    val=v[:n] if mode else None, grid=(40, 40))
+    lost_before = v[:n] < 0
+    aff = np.zeros(cap, np.float32)
+    got = drv.drv_select(which, W, H, _fp(sums[0]), _fp(sums[1]), _fp(sums[2]), win, L, op.borderx, 60, 8, 40, 40, n,
+                         cap, _fp(x), _fp(y), _ip(v), _fp(aff))
+    assert got == len(ex)
+    assert (x[:got] == ex).all() and (y[:got] == ey).all() and (v[:got] == ev).all()
+    assert (ev >= 0).sum() > 20
+    # affine state: reset (-1) in the slots written by KLTReplaceLostFeatures2 / ...Uniform(select), else kept
+    if which == 3:
+        assert (aff[:n][lost_before] == -1).all() and (aff[:n][~lost_before] == 7).all()
+    elif which == 4:
+        assert (aff[:got] == -1).all()
+    elif mode == 1:
+        assert (aff[:n] == 7).all()
+
+
+@pytest.mark.gpu
+def test_shim_smooth_and_gradients_match_oracle(drv, ok):
+    rng = np.random.default_rng(5)
+    img = (rng.random((90, 130)) * 255).astype(np.float32)
+    sm, gx, gy = (np.zeros_like(img) for _ in range(3))
+    assert drv.drv_smooth_grad(130, 90, _fp(img), C.c_float(1.0), _fp(sm), _fp(gx), _fp(gy)) == 0
+    rgx, rgy = ok.gradients(img, 1.0)
+    for a, b in ((sm, ok.smooth(img, 1.0)), (gx, rgx), (gy, rgy)):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
