@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgklt.so")
 SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip",
            "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip", "gklt_select.hip",
-           "gklt_seed.hip", "gklt_ingest.hip", "gklt_ransac.hip"]
+           "gklt_ingest.hip", "gklt_ransac.hip"]
 HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h")]
 
 # -ffp-contract=off: the reference's arithmetic is unfused AVX (no FMA); fusing mul+add on the

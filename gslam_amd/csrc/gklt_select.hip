@@ -825,6 +825,7 @@ __global__ void k_fill_rest(const unsigned *__restrict__ count, unsigned cap,
 // ---------------------------------------------------------------------------------------------
 struct SelScratch {
   int w = 0, h = 0, cap_list = 0, cap_slots = 0;
+  size_t cap_px = 0, cap_sum = 0, cap_tiles = 0;  // allocated sizes: the scratch of a large image serves smaller ones
   float *sum[3] = {nullptr, nullptr, nullptr};  // (h+1) x (w+1)
   unsigned *state = nullptr;
   unsigned char *blocked = nullptr;
@@ -864,7 +865,9 @@ void sel_free(SelScratch *s) {
 
 static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   SelScratch *s = ctx->sel;
-  if (s && (s->w != w || s->h != h || s->cap_slots < nslots)) {
+  const size_t px = (size_t)w * h, sum = (size_t)(w + 1) * (h + 1);
+  const size_t tiles = (size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH);
+  if (s && (s->cap_px < px || s->cap_sum < sum || s->cap_tiles < tiles || s->cap_slots < nslots)) {
     GKLT_HIP(hipDeviceSynchronize());
     sel_free(s);
     s = ctx->sel = nullptr;
@@ -872,35 +875,38 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   if (!s) {
     s = new SelScratch();
     ctx->sel = s;
-    s->w = w;
-    s->h = h;
-    s->cap_list = w * h;  // mindist 1 accepts every candidate
+    s->cap_px = px;
+    s->cap_sum = sum;
+    s->cap_tiles = tiles;
     s->cap_slots = std::max(nslots, 4096);
-    const size_t sb = sizeof(float) * (size_t)(w + 1) * (h + 1);
-    for (auto &p : s->sum) GKLT_HIP(hipMalloc(&p, sb));
-    GKLT_HIP(hipMalloc(&s->state, sizeof(unsigned) * (size_t)w * h));
-    GKLT_HIP(hipMalloc(&s->blocked, (size_t)w * h));
-    GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * (size_t)s->cap_list));
-    GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * (size_t)s->cap_list));
-    s->tile_bytes = sizeof(unsigned) * (size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH);
-    GKLT_HIP(hipMalloc(&s->tile_left, s->tile_bytes));
-    s->ntiles = s->tile_bytes / sizeof(unsigned);
-    GKLT_HIP(hipMalloc(&s->tile_changed, 2 * s->ntiles));
+    for (auto &p : s->sum) GKLT_HIP(hipMalloc(&p, sizeof(float) * sum));
+    GKLT_HIP(hipMalloc(&s->state, sizeof(unsigned) * px));
+    GKLT_HIP(hipMalloc(&s->blocked, px));
+    GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * px));
+    GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * px));
+    GKLT_HIP(hipMalloc(&s->tile_left, sizeof(unsigned) * tiles));
+    GKLT_HIP(hipMalloc(&s->tile_changed, 2 * tiles));
     GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
     GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
     GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
     GKLT_HIP(hipHostMalloc(&s->h_counters, sizeof(unsigned) * (kMaxRounds + 1), hipHostMallocDefault));
   }
+  if (s->w != w || s->h != h) s->last_rounds[0] = s->last_rounds[1] = 0;  // round hint of another image size
+  s->w = w;
+  s->h = h;
+  s->cap_list = (int)px;  // mindist 1 accepts every candidate
+  s->ntiles = tiles;
+  s->tile_bytes = sizeof(unsigned) * tiles;
   *out = s;
   return 0;
 }
 
 int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *py,
-                                  SelScratch *sc) {
-  const int w = py->lv[0].w, h = py->lv[0].h;
+                                  SelScratch *sc, int level = 0) {
+  const int w = py->lv[level].w, h = py->lv[level].h;
   {
     ProfScope ps(ctx, s, GKLT_K_INTEGRAL);
-    hipLaunchKernelGGL(k_integral_rows, dim3((h + kIR - 1) / kIR), dim3(256), 0, s, py->lv[0].tex, w, h,
+    hipLaunchKernelGGL(k_integral_rows, dim3((h + kIR - 1) / kIR), dim3(256), 0, s, py->lv[level].tex, w, h,
                        sc->sum[0], sc->sum[1], sc->sum[2]);
     hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(256), 0, s, sc->sum[0],
                        sc->sum[1], sc->sum[2], w, h);
@@ -911,8 +917,8 @@ int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyram
 
 // S1-S4 on device-resident sums and a device-resident list (x, y, val of n features).
 int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int round2, int n,
-                     float *fx, float *fy, int *fval) {
-  const gklt_params &P = ctx->prm;
+                     float *fx, float *fy, int *fval, const gklt_params *prm = nullptr) {
+  const gklt_params &P = prm ? *prm : ctx->prm;
   const int w = sc->w, h = sc->h;
   const int overwrite = mode == GKLT_SELECT_ALL;
   const int hw = P.window_width / 2, hh = P.window_height / 2;
@@ -1572,6 +1578,59 @@ extern "C" int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *py, int mod
   // replacing with nothing lost is a no-op (:442-447): k_lost_slots yields 0 slots and the
   // fixpoint result is simply not written anywhere, so no host round trip is needed for it
   if (int rc = select_on_device(ctx, s, sc, mode, round2, fl->n, fl->x, fl->y, fl->val)) return rc;
+  GKLT_HIP(hipEventRecord(py->consumed, s));
+  py->has_consumed = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------ keyframe seeding
+namespace {
+// seeds found at `level` in that level's pixels -> level-0 coordinates, alive as KLT_TRACKED
+// (System.cpp:415-420: feature.x = key.pt.x * mScaleFactor, feature.val = KLT_TRACKED)
+__global__ void k_seed_scale(float *__restrict__ x, float *__restrict__ y, int *__restrict__ val, int n,
+                             float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (val[i] >= 0) {
+    x[i] = x[i] * scale;
+    y[i] = y[i] * scale;
+    val[i] = GKLT_TRACKED;
+  }
+}
+}  // namespace
+
+extern "C" int gklt_seed_from_level(gklt_ctx *ctx, gklt_pyramid *py, int level, gklt_flist *fl,
+                                    int nFeatures) {
+  if (!ctx || !py || !fl || py->ctx != ctx || fl->ctx != ctx || level < 0 || level >= py->nlevels)
+    return GKLT_EINVAL;
+  if (nFeatures < 0 || nFeatures > fl->capacity) {
+    set_error("%d seeds exceed the list capacity %d", nFeatures, fl->capacity);
+    return GKLT_ECAPACITY;
+  }
+  GKLT_HIP(hipSetDevice(ctx->device));
+  if (!py->has_ready) {
+    set_error("seeding from a pyramid that was never built");
+    return GKLT_EINVAL;
+  }
+  fl->n = nFeatures;
+  if (nFeatures == 0) return 0;
+  int scale = 1;
+  for (int l = 0; l < level; ++l) scale *= py->ss;  // mScaleFactor = 2^(nPyramidLevels-1), System.cpp:111
+  // selection in the pixels of `level`: the border shrinks with the level so that every seed,
+  // scaled back, lies inside the level-0 border the tracker tests (LK.hpp:886-915)
+  gklt_params P = ctx->prm;
+  P.borderx = (P.borderx + scale - 1) / scale;
+  P.bordery = (P.bordery + scale - 1) / scale;
+  SelScratch *sc;
+  if (int rc = sel_get(ctx, py->lv[level].w, py->lv[level].h, nFeatures, &sc)) return rc;
+  hipStream_t s = ctx->s_trk;
+  GKLT_HIP(hipStreamWaitEvent(s, py->ready, 0));
+  if (int rc = select_integrals_from_pyramid(ctx, s, py, sc, level)) return rc;
+  if (int rc = select_on_device(ctx, s, sc, GKLT_SELECT_ALL, 0, nFeatures, fl->x, fl->y, fl->val, &P))
+    return rc;
+  hipLaunchKernelGGL(k_seed_scale, dim3((nFeatures + 255) / 256), dim3(256), 0, s, fl->x, fl->y, fl->val,
+                     nFeatures, (float)scale);
+  GKLT_HIP(hipGetLastError());
   GKLT_HIP(hipEventRecord(py->consumed, s));
   py->has_consumed = true;
   return 0;

@@ -201,6 +201,23 @@ int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *sumDxx, const
 int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *pyr, int mode, int variant,
                              gklt_flist *fl, int gridW, int gridH);
 
+/* ---- keyframe seeding on the device ---- */
+
+/* System::Track re-seeds the tracked list at every keyframe from keypoints detected on the COARSEST
+ * pyramid image, scaled back by mScaleFactor = subsampling^(nPyramidLevels-1), all alive as
+ * KLT_TRACKED (System.cpp:407-420,672-689); the reference downloads that plane, converts it to 8 bit
+ * and runs the ORB extractor's FAST detector (ORBextractor.cc:807-900, OpenCV's cv::FAST, not in
+ * the reference tree).  gklt_seed_from_level does the step without leaving the GPU, with the
+ * detector this library has, the reference's own Shi-Tomasi selector (KLTSelectGoodFeatures,
+ * selectGoodFeatures.hpp:234-433, the call System.cpp:385-394 keeps commented out): the integral
+ * images of gx^2, gy^2, gx*gy of level `level`, plain selection of nFeatures corners there (window,
+ * mindist, min_eigenvalue, nSkippedPixels of the context in that level's pixels; border =
+ * ceil(border / scale) so that every seed lies inside the level-0 border the tracker tests), then
+ * x *= scale, y *= scale, val = KLT_TRACKED with scale = subsampling^level.  The list gets
+ * nFeatures entries; entries for which no corner was left stay (-1, -1, KLT_NOT_FOUND).
+ * Asynchronous apart from the selector's convergence polls; ordered after the pyramid's build. */
+int gklt_seed_from_level(gklt_ctx *ctx, gklt_pyramid *pyr, int level, gklt_flist *fl, int nFeatures);
+
 /* ---- bearing vectors with per-row rotation ---- */
 
 /* ImageGrids::rotateAndNormalizePoint (ImageGrids.hpp:73-106) applied as NormalizeFrameInvoker

@@ -248,3 +248,21 @@ def select_features(p, mode, variant, sumxx, sumyy, sumxy, nFeatures, x=None, y=
     if rc:
         raise RuntimeError("ok_select_features failed rc=%d" % rc)
     return fx[: n.value].copy(), fy[: n.value].copy(), fv[: n.value].copy()
+
+
+def seed_from_level(p, pyr, level, nFeatures):
+    """Keyframe seeding (System.cpp:407-420,672-689: keypoints of the coarsest level x mScaleFactor,
+    val = KLT_TRACKED) with the Shi-Tomasi selector in place of ORB's FAST detector, as
+    gklt_seed_from_level documents it: plain KLTSelectGoodFeatures (selectGoodFeatures.hpp:424-433)
+    on the integral images (System.cpp:385-392) of level `level`, border = ceil(border / scale)."""
+    scale = p.subsampling ** level
+    q = p.copy()
+    q.borderx = (p.borderx + scale - 1) // scale
+    q.bordery = (p.bordery + scale - 1) // scale
+    sums = integral_products(pyr[3 * level + 1], pyr[3 * level + 2])
+    x, y, v = select_features(q, 0, 0, *sums, nFeatures)
+    found = v >= 0
+    x = np.where(found, x * np.float32(scale), x).astype(np.float32)
+    y = np.where(found, y * np.float32(scale), y).astype(np.float32)
+    v = np.where(found, 0, v).astype(np.int32)
+    return x, y, v
