@@ -166,6 +166,12 @@ int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, 
 // page-locked mirror first, and the H2D copies read from there (gklt_api.hip).
 int flist_upload_staged(gklt_flist *fl, hipStream_t s, size_t off, int n, const float *x,
                         const float *y, const int *val);
+// ingested frames (gklt_ingest.hip): device luma plane of the last ingest once `consumer` may read
+// it; the consumer records when it is done with the plane
+int frame_source(gklt_frame *f, hipStream_t consumer, const uint8_t **luma, int *stride);
+int frame_consumed(gklt_frame *f, hipStream_t consumer);
+gklt_ctx *frame_ctx(gklt_frame *f);
+bool frame_matches(gklt_frame *f, int w, int h);
 // bearing vectors (gklt_bearing.hip); grows ctx->d_norm / d_vec to n entries (gklt_api.hip)
 int ensure_bearing_buffers(gklt_ctx *ctx, int n);
 // all launches of one pyramid build on stream s (gklt_api.hip)

@@ -183,6 +183,22 @@ extern "C" int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int
   return 0;
 }
 
+// gklt_pipeline_step with the next frame taken from an ingested gklt_frame (gklt_ingest.hip)
+extern "C" int gklt_pipeline_step_frame(gklt_pipeline *p, gklt_frame *next, void *host_out) {
+  if (!p || !p->started || !next || frame_ctx(next) != p->ctx) return GKLT_EINVAL;
+  if (!frame_matches(next, p->W, p->H)) {
+    set_error("frame size differs from the pipeline's %dx%d", p->W, p->H);
+    return GKLT_EINVAL;
+  }
+  if (int rc = dev(p)) return rc;
+  hipStream_t sb = p->st[(int)((p->t + 1) & 1)];  // the stream B(t+1) is enqueued on
+  const uint8_t *luma = nullptr;
+  int stride = 0;
+  if (int rc = frame_source(next, sb, &luma, &stride)) return rc;
+  if (int rc = gklt_pipeline_step(p, luma, stride, 1, host_out)) return rc;
+  return frame_consumed(next, sb);
+}
+
 extern "C" int gklt_pipeline_upload_features(gklt_pipeline *p, int n, const float *x,
                                              const float *y, const int *val) {
   if (!p || n < 0 || (n > 0 && (!x || !y || !val))) return GKLT_EINVAL;

@@ -647,3 +647,62 @@ def select_from_pyramid(ctx, pyr, mode, variant, fl, grid=(20, 20)):
 def seed_from_level(ctx, pyr, level, fl, nFeatures):
     """gklt_seed_from_level: keyframe seeds (System.cpp:407-420) selected on pyramid level `level`."""
     _check(lib().gklt_seed_from_level(ctx.h, pyr.h, int(level), fl.h, int(nFeatures)))
+
+
+class Frame:
+    """gklt_frame: a decoded frame on the GPU (Y plane + half-resolution RGB), main.cpp:77-107."""
+
+    def __init__(self, ctx, W, H):
+        self.ctx, self.W, self.H = ctx, W, H
+        self.h = C.c_void_p()
+        _check(lib().gklt_frame_create(ctx.h, W, H, C.byref(self.h)))
+        self._keep = None
+
+    def ingest_nv12(self, y, uv):
+        """y: H x W u8, uv: H/2 x W u8 (interleaved chroma) numpy arrays (host), or
+        ((ptr, stride), (ptr, stride)) device planes."""
+        u8 = C.POINTER(C.c_uint8)
+        if isinstance(y, np.ndarray):
+            y, uv = np.ascontiguousarray(y, np.uint8), np.ascontiguousarray(uv, np.uint8)
+            self._keep = (y, uv)
+            _check(lib().gklt_frame_ingest_nv12(self.ctx.h, self.h, y.ctypes.data_as(u8), y.strides[0],
+                                                uv.ctypes.data_as(u8), uv.strides[0], 0))
+            _check(lib().gklt_sync(self.ctx.h))  # pageable sources: stay alive until staged
+        else:
+            _check(lib().gklt_frame_ingest_nv12(self.ctx.h, self.h, C.cast(C.c_void_p(y[0]), u8), y[1],
+                                                C.cast(C.c_void_p(uv[0]), u8), uv[1], 1))
+
+    def ingest_gray(self, y):
+        y = np.ascontiguousarray(y, np.uint8)
+        self._keep = (y,)
+        _check(lib().gklt_frame_ingest_gray(self.ctx.h, self.h, y.ctypes.data_as(C.POINTER(C.c_uint8)), y.strides[0], 0))
+        _check(lib().gklt_sync(self.ctx.h))
+
+    def luma(self):
+        p, s = C.POINTER(C.c_uint8)(), C.c_int()
+        _check(lib().gklt_frame_luma(self.ctx.h, self.h, C.byref(p), C.byref(s)))
+        return C.cast(p, C.c_void_p).value, s.value
+
+    def color(self):
+        out = np.empty((self.H // 2, self.W // 2, 3), np.uint8)
+        _check(lib().gklt_frame_download_color(self.ctx.h, self.h, out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               out.strides[0]))
+        return out
+
+    def feature_colors(self, fl):
+        out = np.zeros((len(fl), 3), np.uint8)
+        _check(lib().gklt_flist_colors(self.ctx.h, self.h, fl.h, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().gklt_frame_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def pyramid_build_frame(ctx, pyr, frame):
+    _check(lib().gklt_pyramid_build_frame(ctx.h, pyr.h, frame.h))
+
+
+def pipeline_step_frame(pipe, frame, host_out=None):
+    _check(lib().gklt_pipeline_step_frame(pipe.h, frame.h, C.c_void_p(host_out)))

@@ -63,6 +63,7 @@ typedef struct gklt_params {
 typedef struct gklt_ctx gklt_ctx;
 typedef struct gklt_pyramid gklt_pyramid;
 typedef struct gklt_flist gklt_flist;
+typedef struct gklt_frame gklt_frame;
 
 const char *gklt_last_error(void);
 
@@ -272,6 +273,42 @@ int gklt_pipeline_wait_tracked(gklt_pipeline *p);
  * call gklt_pipeline_sync() first. */
 gklt_flist *gklt_pipeline_flist(gklt_pipeline *p);
 gklt_pyramid *gklt_pipeline_pyramid(gklt_pipeline *p, int which);
+
+/* ---- frame ingest (main.cpp:77-107, System.cpp:310-315) ---- */
+
+/* A decoded video frame on the GPU: the 8-bit Y plane that computePyramid reads, and the
+ * half-resolution RGB image System keeps for point colours.  The reference gets frames as NV12
+ * pixel buffers (plane 0 = Y, W x H; plane 1 = interleaved chroma, W/2 x H/2 two-byte samples),
+ * copies the Y plane (image.copyTo, main.cpp:99,101) and builds the colour image on the host
+ * with cv::split / cv::resize / cv::merge / cv::cvtColor(CV_YCrCb2RGB) (main.cpp:84-93).
+ * gklt_frame_ingest_nv12 moves both planes H2D once (1.5 bytes per pixel; on_device = 1: the planes
+ * already are device memory, e.g. a hardware decoder's output, and are borrowed until consumed) and
+ * forms the colour image with one kernel: Y' = 2x2 area mean (a+b+c+d+2)>>2, the two chroma bytes
+ * in memory order as channels 1 and 2, OpenCV's 8-bit YCrCb->RGB fixed-point formula (channel 1
+ * read as Cr, as the reference's merge order makes it).  gklt_frame_ingest_gray takes a Y plane
+ * only (no colour image).  Asynchronous on the context's pyramid stream; a frame is re-ingested
+ * only after the build that consumed it has finished reading (event-ordered), so two frames
+ * alternate without host waits.  width and height must be even. */
+int gklt_frame_create(gklt_ctx *ctx, int width, int height, gklt_frame **out);
+int gklt_frame_destroy(gklt_frame *f);
+int gklt_frame_ingest_nv12(gklt_ctx *ctx, gklt_frame *f, const uint8_t *y, int y_stride,
+                           const uint8_t *uv, int uv_stride, int on_device);
+int gklt_frame_ingest_gray(gklt_ctx *ctx, gklt_frame *f, const uint8_t *y, int y_stride,
+                           int on_device);
+/* computePyramid(tc, frame's Y plane, pyramid) (pyramid.cpp:45), ordered after the ingest. */
+int gklt_pyramid_build_frame(gklt_ctx *ctx, gklt_pyramid *pyr, gklt_frame *f);
+/* gklt_pipeline_step with the next frame taken from `next` (ordered after its ingest). */
+int gklt_pipeline_step_frame(struct gklt_pipeline *p, gklt_frame *next, void *host_out);
+/* Device address and row stride of the ingested Y plane (for the img_on_device = 1 entry points);
+ * waits for the ingest. */
+int gklt_frame_luma(gklt_ctx *ctx, gklt_frame *f, const uint8_t **device_ptr, int *stride);
+/* The colour image, (H/2) rows of (W/2) RGB triples, to host; stride in bytes.  Synchronous. */
+int gklt_frame_download_color(gklt_ctx *ctx, gklt_frame *f, uint8_t *rgb, int stride);
+/* Point colours at a keyframe (NormalizeKeyFrameInvoker, System.cpp:310-315): for every entry of
+ * the device list with val >= 0, rgb_out[3i..3i+2] = colour image at (round(y/2), round(x/2))
+ * (indices clamped to the image; the reference does not test them); (0,0,0) for dead entries.
+ * rgb_out: 3 * size bytes of host memory.  Synchronous. */
+int gklt_flist_colors(gklt_ctx *ctx, gklt_frame *f, gklt_flist *fl, uint8_t *rgb_out);
 
 /* ---- lookahead pipeline: the same frame loop with a deeper preload ---- */
 

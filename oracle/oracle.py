@@ -266,3 +266,38 @@ def seed_from_level(p, pyr, level, nFeatures):
     y = np.where(found, y * np.float32(scale), y).astype(np.float32)
     v = np.where(found, 0, v).astype(np.int32)
     return x, y, v
+
+
+def ingest_nv12(y, uv):
+    """main.cpp:77-93 in integers: -> (luma, rgb_half).  luma is the Y plane itself (image.copyTo);
+    rgb_half = cvtColor(merge(resize(Y, 1/2), split(uv)[0], split(uv)[1]), CV_YCrCb2RGB): 2x2 area
+    mean (a+b+c+d+2)>>2 (cv::resize INTER_LINEAR at exactly 1/2, 8 bit), channel 1 read as Cr and
+    channel 2 as Cb, OpenCV's 8-bit fixed-point YCrCb->RGB (coefficients 22987, -11698, -5636, 29049,
+    shift 14, round half up, saturate).  OpenCV is not vendored: parity with it is unpinned."""
+    y = np.ascontiguousarray(y, np.uint8)
+    uv = np.ascontiguousarray(uv, np.uint8)
+    H, W = y.shape
+    assert uv.shape == (H // 2, W)
+    yi = y.astype(np.int32)
+    Y = (yi[0::2, 0::2] + yi[0::2, 1::2] + yi[1::2, 0::2] + yi[1::2, 1::2] + 2) >> 2
+    cr = uv[:, 0::2].astype(np.int32) - 128
+    cb = uv[:, 1::2].astype(np.int32) - 128
+    r = Y + ((cr * 22987 + 8192) >> 14)
+    g = Y + ((cb * -5636 + cr * -11698 + 8192) >> 14)
+    b = Y + ((cb * 29049 + 8192) >> 14)
+    rgb = np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
+    return y, rgb
+
+
+def feature_colors(rgb, x, y, val):
+    """NormalizeKeyFrameInvoker's colour lookup (System.cpp:310-315): rgb[round(y/2), round(x/2)] for
+    live features (C round(): half away from zero; y/2 in fp32); indices clamped; dead -> 0."""
+    h2, w2 = rgb.shape[:2]
+    def rnd(a):
+        a = (np.asarray(a, np.float32) / np.float32(2)).astype(np.float64)
+        return (np.sign(a) * np.floor(np.abs(a) + 0.5)).astype(np.int64)
+    r = np.clip(rnd(y), 0, h2 - 1)
+    c = np.clip(rnd(x), 0, w2 - 1)
+    out = rgb[r, c].copy()
+    out[np.asarray(val) < 0] = 0
+    return out
