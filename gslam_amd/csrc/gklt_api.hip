@@ -151,6 +151,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
   if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
   sel_free(ctx->sel);
+  ransac_free(ctx->ransac);
   (void)hipFree(ctx->d_frame);
   (void)hipFree(ctx->d_invk);
   (void)hipFree(ctx->d_norm);

@@ -52,11 +52,14 @@ struct Level {
 namespace gklt {
 struct SelScratch;  // selector scratch (gklt_select.hip)
 void sel_free(SelScratch *s);
+struct RansacScratch;  // outlier-rejection scratch (gklt_ransac.hip)
+void ransac_free(RansacScratch *r);
 }  // namespace gklt
 
 struct gklt_ctx {
   int device = 0;
   gklt::SelScratch *sel = nullptr;
+  gklt::RansacScratch *ransac = nullptr;
   gklt_params prm{};
   hipStream_t s_pyr = nullptr;  // pyramid builds
   hipStream_t s_trk = nullptr;  // tracker, feature list copies

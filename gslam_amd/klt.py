@@ -15,9 +15,9 @@ LIB_PATH = os.environ.get("GKLT_LIB") or os.path.join(_HERE, "libgklt.so")  # GK
 
 KLT_TRACKED, KLT_NOT_FOUND, KLT_SMALL_DET = 0, -1, -2
 KLT_MAX_ITERATIONS, KLT_OOB, KLT_LARGE_RESIDUE = -3, -4, -5
-K_SMOOTH0, K_DOWN, K_GRAD, K_TRACK, K_MISC, K_INTEGRAL, K_SELECT, K_LEVEL0, K_LEVELN = range(9)
+K_SMOOTH0, K_DOWN, K_GRAD, K_TRACK, K_MISC, K_INTEGRAL, K_SELECT, K_LEVEL0, K_LEVELN, K_RANSAC = range(10)
 KERNEL_NAMES = {K_SMOOTH0: "smooth0", K_DOWN: "down", K_GRAD: "grad", K_TRACK: "track", K_MISC: "misc",
-                K_INTEGRAL: "integral", K_SELECT: "select", K_LEVEL0: "level0", K_LEVELN: "leveln"}
+                K_INTEGRAL: "integral", K_SELECT: "select", K_LEVEL0: "level0", K_LEVELN: "leveln", K_RANSAC: "ransac"}
 
 
 class GkltError(RuntimeError):
@@ -706,3 +706,23 @@ def pyramid_build_frame(ctx, pyr, frame):
 
 def pipeline_step_frame(pipe, frame, host_out=None):
     _check(lib().gklt_pipeline_step_frame(pipe.h, frame.h, C.c_void_p(host_out)))
+
+
+def relative_ransac(ctx, key_norm, cur_norm, val, is_valid, R, K, min_view_angle, med_view_angle, threshold=10.0,
+                    prob=0.98, max_iters=1000, seed=0):
+    """gklt_relative_ransac (Estimation.cpp:621-683) -> (inliers or -1, is_valid after, F, examined)."""
+    kn = np.ascontiguousarray(key_norm, np.float64).reshape(-1, 3)
+    cn = np.ascontiguousarray(cur_norm, np.float64).reshape(-1, 3)
+    val = np.ascontiguousarray(val, np.int32)
+    valid = np.array(is_valid, np.uint8)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    F = np.zeros(9)
+    inl, it = C.c_int(), C.c_int()
+    dp = C.POINTER(C.c_double)
+    _check(lib().gklt_relative_ransac(
+        ctx.h, len(val), kn.ctypes.data_as(dp), cn.ctypes.data_as(dp), _ip(val),
+        valid.ctypes.data_as(C.POINTER(C.c_uint8)), R.ctypes.data_as(dp), K.ctypes.data_as(dp),
+        C.c_double(min_view_angle), C.c_double(med_view_angle), C.c_double(threshold), C.c_double(prob),
+        int(max_iters), C.c_uint64(seed), C.byref(inl), F.ctypes.data_as(dp), C.byref(it)))
+    return inl.value, valid, F.reshape(3, 3), it.value

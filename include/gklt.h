@@ -274,6 +274,32 @@ int gklt_pipeline_wait_tracked(gklt_pipeline *p);
 gklt_flist *gklt_pipeline_flist(gklt_pipeline *p);
 gklt_pyramid *gklt_pipeline_pyramid(gklt_pipeline *p, int which);
 
+/* ---- geometric outlier rejection on the tracks ---- */
+
+/* RelativeOutlierRejection::relativeRansac (Estimation.cpp:621-683; System.cpp:550-564 calls it
+ * after every KLTTrackFeatures with threshold 10 px and prob 0.98).  Host arrays: key_norm3 =
+ * bearing of every feature in the keyframe (mvLocalMapPoints[i].norm), cur_norm3 = its bearing in
+ * the current frame (feature[i]->norm, e.g. from gklt_rotate_normalize), n x 3 doubles each; val =
+ * the list's status; is_valid = n flags, updated in place; R = rotation keyframe -> current frame
+ * (row-major; its transpose is applied to cur_norm3), K = camera matrix (row-major); the view angles
+ * are cosines as in SLAMSettings.  As the reference: candidates are the entries with val ==
+ * KLT_TRACKED and is_valid; a candidate whose view angle p1.p2 is >= min_view_angle loses is_valid
+ * and is skipped; if fewer than half of the candidates lie below med_view_angle *inliers = -1 and
+ * nothing else happens; otherwise a fundamental matrix is fitted to the K-projected pixel pairs by
+ * RANSAC and the pairs it rejects lose is_valid; *inliers = number of pairs it keeps (0 with fewer
+ * than 7 pairs).  The RANSAC (cv::findFundamentalMat in the reference -- OpenCV's sampler is not
+ * part of the reference tree, so its random choices cannot be reproduced) is this library's:
+ * 7-point minimal solver, larger squared point-to-epipolar-line distance <= threshold^2, adaptive
+ * iteration count for confidence `prob` capped at max_iters (OpenCV: 1000), counter-based sampler
+ * seeded by `seed`; all max_iters hypotheses are evaluated in parallel and the sequential
+ * bookkeeping is replayed on the host, so the result is that of the sequential algorithm
+ * (oracle/ransac_oracle.c).  F_out (may be NULL): the best matrix, pixels, x2^T F x1 = 0, row-major;
+ * iters_out (may be NULL): hypotheses the adaptive loop examined.  Synchronous. */
+int gklt_relative_ransac(gklt_ctx *ctx, int n, const double *key_norm3, const double *cur_norm3,
+                         const int *val, uint8_t *is_valid, const double *R, const double *K,
+                         double min_view_angle, double med_view_angle, double threshold, double prob,
+                         int max_iters, uint64_t seed, int *inliers, double *F_out, int *iters_out);
+
 /* ---- frame ingest (main.cpp:77-107, System.cpp:310-315) ---- */
 
 /* A decoded video frame on the GPU: the 8-bit Y plane that computePyramid reads, and the
@@ -431,7 +457,8 @@ enum {
   GKLT_K_SELECT = 6,   /* score, suppression rounds, rank/assign */
   GKLT_K_LEVEL0 = 7,   /* fused level 0: u8 -> smooth -> texels + level 1 */
   GKLT_K_LEVELN = 8,   /* fused level l > 0: I_l -> texels + level l+1 */
-  GKLT_K_COUNT = 9
+  GKLT_K_RANSAC = 9,   /* outlier rejection: prepare, hypotheses, scoring */
+  GKLT_K_COUNT = 10
 };
 /* When enabled, every kernel launch is bracketed by HIP events on its own stream. */
 int gklt_profile_enable(gklt_ctx *ctx, int on);

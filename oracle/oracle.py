@@ -48,8 +48,8 @@ class Params(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(
-        os.path.join(_HERE, "klt_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("klt_oracle.c", "ransac_oracle.c")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libklt_oracle.so"], stdout=subprocess.DEVNULL)
 
@@ -301,3 +301,24 @@ def feature_colors(rgb, x, y, val):
     out = rgb[r, c].copy()
     out[np.asarray(val) < 0] = 0
     return out
+
+
+def relative_ransac(key_norm, cur_norm, val, is_valid, R, K, min_view_angle, med_view_angle, threshold=10.0,
+                    prob=0.98, max_iters=1000, seed=0):
+    """RelativeOutlierRejection::relativeRansac (Estimation.cpp:621-683; System.cpp:550-564 sets
+    threshold 10, prob 0.98).  -> (inlier count or -1, is_valid after, F in pixels, hypotheses examined)."""
+    kn = np.ascontiguousarray(key_norm, np.float64).reshape(-1, 3)
+    cn = np.ascontiguousarray(cur_norm, np.float64).reshape(-1, 3)
+    val = np.ascontiguousarray(val, np.int32)
+    valid = np.array(is_valid, np.uint8)
+    R = np.ascontiguousarray(R, np.float64).reshape(9)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    F = np.zeros(9)
+    it = C.c_int()
+    dp = C.POINTER(C.c_double)
+    f = lib().ok_relative_ransac
+    f.restype = C.c_int
+    rc = f(len(val), kn.ctypes.data_as(dp), cn.ctypes.data_as(dp), _ip(val), valid.ctypes.data_as(C.POINTER(C.c_uint8)),
+           R.ctypes.data_as(dp), K.ctypes.data_as(dp), C.c_double(min_view_angle), C.c_double(med_view_angle),
+           C.c_double(threshold), C.c_double(prob), int(max_iters), C.c_uint64(seed), F.ctypes.data_as(dp), C.byref(it))
+    return rc, valid, F.reshape(3, 3), it.value
