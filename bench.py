@@ -66,6 +66,7 @@ def parse(argv=None):
                          "each per call, no lookahead); a step is then one frame of every stream")
     ap.add_argument("--track-waves", type=int, default=0, help="wavefronts per tracker launch (0 = library default)")
     ap.add_argument("--track-impl", type=int, default=0, help="gklt_ctx_set_track_impl (A/B runs; 0 = default)")
+    ap.add_argument("--pyramid-impl", type=int, default=0, help="gklt_ctx_set_pyramid_impl (A/B runs; 0 = default)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a 1-GPU box: every rank uses device 0 (numbers are not a scaling result)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -721,6 +722,7 @@ def main(argv=None):
     ctx = klt.Context(device, gp)
     ctx.set_track_waves(a.track_waves)
     ctx.set_track_impl(a.track_impl)
+    ctx.set_pyramid_impl(a.pyramid_impl)
     if "select" in cfg and not a.streams:
         return main_c5(a, ctx, cfg, dist, rank, world)
     if a.streams > 0:

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libgklt.so")
-SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_track.hip", "gklt_pipeline.hip",
+SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_pyramid_stream.hip", "gklt_track.hip", "gklt_pipeline.hip",
            "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip", "gklt_select.hip",
            "gklt_ingest.hip", "gklt_ransac.hip"]
 HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h")]

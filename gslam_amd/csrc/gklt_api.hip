@@ -855,7 +855,7 @@ extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
 
 // 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels
 extern "C" int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl) {
-  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->pyr_impl = impl;
   return 0;
 }

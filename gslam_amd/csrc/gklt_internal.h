@@ -74,7 +74,7 @@ struct gklt_ctx {
   int d_rot_capacity = 0;   // in doubles
   void *noalloc_scratch = nullptr;  // this GPU's address of gklt_api.hip's `scratch` array
   // profiling
-  int pyr_impl = 0;    // 0 = fused level kernels when the radii allow, 1 = separate kernels
+  int pyr_impl = 0;    // gklt_ctx_set_pyramid_impl: 0 default, 1 separate kernels, 2 tile kernels, 3 streaming kernels
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
   int sel_impl = 0;         // plain selector rounds: 0 = 32-bit keys, 1 = 64-bit keys
   int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch
@@ -147,6 +147,10 @@ bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d
 int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out);
+// streaming form of the fused level kernel (gklt_pyramid_stream.hip)
+bool level_streamable(int w, int h, int level, const Taps &s0);
+int launch_level_stream(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src, int n,
+                        int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g, const Taps &d);
 int launch_tex_extract(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, int comp, float *dst);
 int launch_tex_to_u8(gklt_ctx *ctx, hipStream_t s, const Texel *tex, int n, uint8_t *dst);
 int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp, const float *src);

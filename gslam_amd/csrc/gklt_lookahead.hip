@@ -190,14 +190,18 @@ extern "C" int gklt_lookahead_submit(gklt_lookahead *p, const uint8_t *const *fr
     set_error("context levels/subsampling changed after the lookahead pipeline was created");
     return GKLT_EINVAL;
   }
-  // P: build this batch.  Its ring slots were last read by the tracker launch of the PREVIOUS
-  // call (e_tracked still holds that record: the wait is enqueued before the re-record below), so
-  // the build does not wait for the launch enqueued next and overlaps it.
+  // P: this batch's build.  Its ring slots were last read by the tracker launch of the PREVIOUS
+  // call: e_tracked still holds that record, so the wait is enqueued here, before the launch below
+  // re-records the event -- the build does not wait for that launch and overlaps it.
   if (p->has_tracked) GKLT_HIP(hipStreamWaitEvent(p->sp, p->e_tracked, 0));
-  if (int rc = enqueue_batch_build(p, p->built + 1, frames, n, stride, on_device)) return rc;
-  // T: track the batch submitted by the previous call; waits for e_built's previous record (that
-  // batch's build), which is why e_built is re-recorded only afterwards
+  // T: track the batch submitted by the previous call (waits for e_built's previous record, that
+  // batch's build; e_built is re-recorded only after this batch's build has been enqueued).  The
+  // tracker launch goes out FIRST: its wavefronts (one per feature, ~64 VGPRs) then hold their four
+  // slots per SIMD before the build's larger wavefronts arrive and take what is left; the other way
+  // round the build can fill the register files and the tracker, whose serial chains set the
+  // pace of the batch, starts late.
   if (int rc = enqueue_pending_track(p)) return rc;
+  if (int rc = enqueue_batch_build(p, p->built + 1, frames, n, stride, on_device)) return rc;
   GKLT_HIP(hipEventRecord(p->e_built, p->sp));
   p->has_built = true;
   for (int i = 0; i < n; ++i) {

@@ -869,6 +869,12 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out) {
   if (n < 1 || n > GKLT_MAX_LOOKAHEAD || (img0_out && n != 1)) return GKLT_EINVAL;
+  // pyr_impl 3: the streaming form of the kernel (gklt_pyramid_stream.hip; same bits).  Alone it is
+  // faster than the tile kernel on batched level-0 launches (131 vs 161 us per 16 C2 frames), but
+  // next to the tracker launch a batch overlaps with it does not shorten the batch,
+  // so the tile kernel stays the default.
+  if (!img0_out && ctx->pyr_impl == 3 && level_streamable(py[0]->lv[level].w, py[0]->lv[level].h, level, s0))
+    return launch_level_stream(ctx, s, py, src, n, stride, level, s0, pyr, g, d);
   LevelIO io{};
   const Level &L = py[0]->lv[level];
   int w2 = 0, h2 = 0;

@@ -432,9 +432,12 @@ int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
  * (4 per SIMD) for the multi-frame launches of the lookahead pipeline, so that the
  * pyramid build it overlaps with always finds room.  Results do not depend on it. */
 int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
-/* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level) when the
- * kernel radii are the reference's defaults, separate kernels otherwise (default); 1 = always
- * the separate smooth / decimate / gradient kernels.  Identical results. */
+/* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level; 64 x 32
+ * tiles) when the kernel radii are the reference's defaults, separate kernels otherwise
+ * (default); 1 = always the separate smooth / decimate / gradient kernels; 2 = as 0; 3 = fused
+ * launches take the streaming kernel (one wavefront per 112-column strip marching down the rows,
+ * column windows in registers) where it applies (frames of at least 192 x 192, level-0 windows
+ * 7x7 / 11x11 / 21x21).  Identical results. */
 int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
 /* Plain / ...2 selector rounds: 0 = 32-bit keys in LDS (default), 1 = the 64-bit-key rounds the
  * Uniform selector uses.  Identical results. */

@@ -169,3 +169,31 @@ def test_coarsest_level_as_u8(klt, ok, gpu_ctx):
         assert list(pyr.plane_u8(2).flat[:8]) == [0, 2, 2, 0, 254, 255, 255, 127]
     finally:
         pyr.close()
+
+
+@pytest.mark.parametrize("impl", [2, 3])
+@pytest.mark.parametrize("H,W,win,L", [
+    (192, 320, 7, 4),      # smallest frame the streaming kernel takes; coarser levels fall to the tile kernel
+    (1080, 1920, 7, 4),    # C2: level-0 radius 2 (odd strip offset: 2x2 blocks straddle lane 63 | lane 0)
+    (1080, 1920, 21, 2),   # as shipped: level-0 radius 6, 13-row unroll
+    (400, 600, 11, 3),     # radius 3
+    (431, 777, 7, 3),      # odd sizes: the exact-2x rule sends level 1 through the generic resize
+    (238, 1999, 11, 2),    # last strip nearly empty; one segment
+])
+def test_fused_level_kernels_tile_and_streaming(klt, ok, H, W, win, L, impl):
+    """gklt_ctx_set_pyramid_impl 2 (tile kernel) and 3 (streaming kernel, which batched builds use by
+    default) produce the oracle's planes bit for bit."""
+    T = synth.base_texture(H, W, seed=17)
+    f = synth.render_frame(T, H, W, 0, seed=17)
+    gp = klt.make_params(window=win, levels=L)
+    ctx = klt.Context(0, gp)
+    ctx.set_pyramid_impl(impl)
+    py = klt.Pyramid(ctx, W, H)
+    py.build(f)
+    ok.set_threads(8)
+    ref = ok.compute_pyramid(ok.make_params(window=win, levels=L), f)
+    ok.set_threads(1)
+    for i, (a, b) in enumerate(zip(py.planes(), ref)):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all(), (impl, i)
+    py.close()
+    ctx.close()
