@@ -17,6 +17,7 @@
 //      acceptances, i.e. it keeps the nFeatures highest-priority members of that set:
 //      k_rank_assign ranks the accepted set and writes slot[rank].
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -433,6 +434,14 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
   }
 }
 
+// cell grid of the Uniform selector as k_mis32_round<R, true> takes it (see there)
+constexpr int kU32Cells = 32, kU32ScoreBits = 26;
+struct U32Grid {
+  int gw, gh, cw, ch;
+  const unsigned short *rank;
+  unsigned *need64;
+};
+
 // counters[round] = undecided candidates left after this round (summed over tiles)
 template <int R>
 __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, 
                                                   unsigned *__restrict__ tile_left,
                                                   const unsigned char *__restrict__ prev_changed,
                                                   unsigned char *__restrict__ cur_changed,
-                                                  int gate, int max_local, int round) {
+                                                  int gate, int max_local, int round, U32Grid) {
   mis_round_tile<R>(
       state, w, h, r, counters + round, tile_left, prev_changed, cur_changed, gate, max_local,
       [](unsigned s, int x, int y) { return prio_key(s, x, y); },
@@ -519,13 +528,23 @@ __device__ __forceinline__ int exact_window(const unsigned *key, int li, int S, 
   return covered ? kRejected : (higher ? kStays : kAcceptedNow);
 }
 
-template <int R>
+// UNI: the uncapped phase of the Uniform selector on the same 32-bit keys.  Its priority is (visiting
+// rank of the cell asc, score desc, y asc, x asc) -- 63 bits in k_u_round's keys -- but a tile only
+// ever compares candidates of the few cells that meet its haloed region (at most kU32Cells), so the
+// cell part shrinks to the DENSE rank among those, 5 bits, and the score keeps 26:
+//   ((31 - dense rank) << 26 | score) << 1        undecided candidate, bit 0 = tie flag as above
+// Equal keys are then equal scores in one cell, which raster order decides as in the plain
+// selector.  A score of 2^26 or more does not fit: the tile raises *need64 and the host repeats the
+// phase with the 64-bit kernel (k_u_round).
+
+template <int R, bool UNI = false>
 __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state, int w, int h,
                                                     int r_rt, unsigned *__restrict__ counters,
                                                     unsigned *__restrict__ tile_left,
                                                     const unsigned char *__restrict__ prev_changed,
                                                     unsigned char *__restrict__ cur_changed,
-                                                    int gate, int max_local, int round) {
+                                                    int gate, int max_local, int round,
+                                                    U32Grid ug) {
   extern __shared__ __align__(16) unsigned lds32[];
   const int r = R >= 0 ? R : r_rt;
   const int inW = MW + 2 * r, inH = MH + 2 * r, S = mis_stride(r), SR = MW + 1;
@@ -581,15 +600,43 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
     blk_left[0] = blk_left[1] = 0;
     blk_changed[0] = blk_changed[1] = 0;
   }
+  // UNI: dense visiting ranks of the cells that meet the haloed tile
+  __shared__ unsigned short cell_rank[kU32Cells];
+  __shared__ unsigned char cell_field[kU32Cells];
+  int cx0 = 0, cy0 = 0, ncx = 1;
+  if constexpr (UNI) {
+    cx0 = min(max(x0 - r, 0) / ug.gw, ug.cw - 1);
+    cy0 = min(max(y0 - r, 0) / ug.gh, ug.ch - 1);
+    const int cx1 = min(min(x0 + MW + r - 1, w - 1) / ug.gw, ug.cw - 1);
+    const int cy1 = min(min(y0 + MH + r - 1, h - 1) / ug.gh, ug.ch - 1);
+    ncx = cx1 - cx0 + 1;
+    const int nreg = ncx * (cy1 - cy0 + 1);  // <= kU32Cells (checked on the host)
+    if ((int)threadIdx.x < nreg)
+      cell_rank[threadIdx.x] = ug.rank[(cy0 + (int)threadIdx.x / ncx) * ug.cw + cx0 + (int)threadIdx.x % ncx];
+    __syncthreads();
+    if ((int)threadIdx.x < nreg) {
+      int dns = 0;
+      for (int j = 0; j < nreg; ++j) dns += cell_rank[j] < cell_rank[threadIdx.x];
+      cell_field[threadIdx.x] = (unsigned char)(kU32Cells - 1 - dns);
+    }
+  }
   __syncthreads();
   int mine = 0, intmax = 0;
   auto put = [&](int tx, int ty, unsigned sval) {
     const bool a = (sval & kAccepted) != 0;
-    key[ty * S + tx] = sval == 0 ? 0u : (a ? 0xFFFFFFFFu : sval << 1);
+    unsigned k = sval == 0 ? 0u : (a ? 0xFFFFFFFFu : sval << 1);
     if (sval != 0 && !a) {
-      intmax |= sval == 0x7FFFFFFFu;
+      if constexpr (UNI) {
+        const int x = x0 - r + tx, y = y0 - r + ty;  // inside the image: sval != 0
+        const int c = (min(y / ug.gh, ug.ch - 1) - cy0) * ncx + min(x / ug.gw, ug.cw - 1) - cx0;
+        if (sval >> kU32ScoreBits) intmax = 1;  // does not fit: the host repeats the phase
+        k = ((unsigned)cell_field[c] << kU32ScoreBits | (sval & ((1u << kU32ScoreBits) - 1))) << 1;
+      } else {
+        intmax |= sval == 0x7FFFFFFFu;
+      }
       if (tx >= r && tx < r + MW && ty >= r && ty < r + MH) mine = 1;
     }
+    key[ty * S + tx] = k;
   };
 #pragma unroll
   for (int u = 0; u < kStage; ++u)
@@ -600,7 +647,10 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
     put(tx, ty, (x >= 0 && x < w && y >= 0 && y < h) ? state[(size_t)y * w + x] : 0u);
   }
   if (mine) any_undecided = 1;
-  if (intmax) scan_all = 1;
+  if (intmax) {
+    if constexpr (UNI) *ug.need64 = 1;
+    else scan_all = 1;
+  }
   __syncthreads();
   if (!any_undecided) {
     if (threadIdx.x == 0) {
@@ -651,7 +701,8 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
         // exact_window of other threads may read this entry during the pass: they see the pixel
         // undecided or decided, and either is a state the rule is safe on (see mis_round_tile)
         key[li] = d == kAcceptedNow ? 0xFFFFFFFFu : 0u;
-        state[(size_t)(y0 + ty) * w + x0 + tx] = d == kAcceptedNow ? ((own >> 1) | kAccepted) : 0u;
+        const unsigned score = UNI ? ((own >> 1) & ((1u << kU32ScoreBits) - 1)) : (own >> 1);
+        state[(size_t)(y0 + ty) * w + x0 + tx] = d == kAcceptedNow ? (score | kAccepted) : 0u;
         changed = 1;
       }
     }
@@ -983,7 +1034,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
         hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
                            sc->tile_left, sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
                            sc->tile_changed + (round & 1) * sc->ntiles, 1, ctx->sel_local_iters,
-                           round);
+                           round, U32Grid{});
     }
     GKLT_HIP(hipGetLastError());
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
@@ -1189,6 +1240,7 @@ __global__ void k_u_fill(int from, int to, float *__restrict__ fx, float *__rest
   }
 }
 
+
 }  // namespace
 
 struct UniScratch {
@@ -1222,7 +1274,7 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
     GKLT_HIP(hipMalloc(&u->state0, sizeof(unsigned) * px));
     GKLT_HIP(hipMalloc(&u->pos, sizeof(unsigned) * (size_t)sc->cap_list));
     GKLT_HIP(hipMalloc(&u->rank, sizeof(unsigned) * (size_t)sc->cap_list));
-    GKLT_HIP(hipMalloc(&u->flags, 2 * sizeof(unsigned)));
+    GKLT_HIP(hipMalloc(&u->flags, 4 * sizeof(unsigned)));  // tail flags [0..1], need64 [2]
     GKLT_HIP(hipMalloc(&u->cellmax, sizeof(unsigned long long) * ncell));
     GKLT_HIP(hipMalloc(&u->tinfo, 4 * sizeof(unsigned long long)));
     GKLT_HIP(hipMalloc(&u->cellcount, sizeof(int) * ncell));
@@ -1234,16 +1286,17 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
 
 // runs fixpoint rounds until no candidate is undecided
 static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
-                      UCaps caps, int r, int *round_io) {
+                      UCaps caps, int r, int *round_io, bool keys32 = false) {
   const int w = sc->w, h = sc->h;
-  const size_t lds = mis_lds_bytes(r);
+  const size_t lds = keys32 ? mis32_lds_bytes(r) : mis_lds_bytes(r);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", r, lds);
     return GKLT_EINVAL;
   }
   auto kern = r == 10 ? k_u_round<10> : k_u_round<-1>;
+  auto kern32 = r == 10 ? k_mis32_round<10, true> : k_mis32_round<-1, true>;
   if (lds > 48 * 1024)
-    GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+    GKLT_HIP(hipFuncSetAttribute(keys32 ? reinterpret_cast<const void *>(kern32) : reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH), pgrid((w + 255) / 256, h);
   GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));  // a phase starts: all tiles live
@@ -1251,22 +1304,31 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
   // with caps a decision also depends on the cell's counters and maximum, which change without
   // any tile of the neighbourhood changing: no gating there
   const int gate = caps.enabled ? 0 : 1;
+  const U32Grid ug{g.gw, g.gh, g.cw, g.ch, g.rank, u->flags + 2};
+  const int phase = caps.enabled ? 1 : 0;
   int round = *round_io;
   bool done = false;
   while (!done) {
     const int first = round;
     {
       ProfScope ps(ctx, s, GKLT_K_SELECT);
-      for (int b = 0; b < kRoundBatch && round <= kMaxRounds; ++b, ++round) {
+      // first batch: what this phase needed in the previous selection plus a margin (video: the
+      // count hardly changes from frame to frame); a converged launch costs a few us, a sync ~25
+      const int nbatch = first == 1 && sc->last_rounds[phase] > 0
+                             ? std::min(std::max(sc->last_rounds[phase] + 2, 4), kRoundBatch) : kRoundBatch;
+      for (int b = 0; b < nbatch && round <= kMaxRounds; ++b, ++round) {
         if (caps.enabled) {
           GKLT_HIP(hipMemsetAsync(u->cellmax, 0, sizeof(unsigned long long) * u->ncell, s));
           hipLaunchKernelGGL(k_u_cellmax, pgrid, dim3(256), 0, s, sc->state, w, h, g, u->cellmax);
         }
-        hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps,
-                           sc->counters, sc->tile_left,
-                           sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
-                           sc->tile_changed + (round & 1) * sc->ntiles, gate, ctx->sel_local_iters,
-                           round);
+        unsigned char *const prev = sc->tile_changed + ((round - 1) & 1) * sc->ntiles;
+        unsigned char *const cur = sc->tile_changed + (round & 1) * sc->ntiles;
+        if (keys32)
+          hipLaunchKernelGGL(kern32, grid, dim3(MT), lds, s, sc->state, w, h, r, sc->counters, sc->tile_left, prev,
+                             cur, gate, ctx->sel_local_iters, round, ug);
+        else
+          hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps, sc->counters,
+                             sc->tile_left, prev, cur, gate, ctx->sel_local_iters, round);
       }
     }
     GKLT_HIP(hipGetLastError());
@@ -1276,7 +1338,7 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     for (int k = first; k < round && !done; ++k)
       if (sc->h_counters[k] == 0) {
         done = true;
-        sc->last_rounds[caps.enabled ? 1 : 0] = k;
+        sc->last_rounds[phase] = k;
       }
     if (!done && round > kMaxRounds) {
       set_error("uniform selection did not converge in %d rounds", kMaxRounds);
@@ -1341,7 +1403,27 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
 
   int round = 1;
   UCaps nocaps{0, 0, 0, 0, nullptr, nullptr};
-  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round)) return rc;  // phase A
+  // Phase A on 32-bit keys when a haloed tile meets at most kU32Cells cells (select impl 1: always
+  // the 64-bit keys), repeated on 64-bit keys in the rare case that a score does not fit 26 bits.
+  // (A cell-by-cell schedule -- one wavefront per cell in visiting order, waiting for its
+  // lower-ranked neighbours -- was built and dropped: the longest chain of dependent cells of the
+  // centre-out order is 93 cells on the 60 x 33 grid of a 1080p frame, and a lone wavefront needs
+  // several microseconds per cell: 12 ms, against 0.64 ms for these rounds.)
+  const int tcx = (MW + 2 * r - 2) / gridW + 2, tcy = (MH + 2 * r - 2) / gridH + 2;
+  const bool keys32 = ctx->sel_impl != 1 && tcx * tcy <= kU32Cells;
+  if (keys32) GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
+  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys32)) return rc;
+  if (keys32) {
+    unsigned need64 = 0;
+    GKLT_HIP(hipMemcpyAsync(&need64, u->flags + 2, sizeof need64, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    if (need64) {
+      GKLT_HIP(hipMemcpyAsync(sc->state, u->state0, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
+      GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
+      round = 1;
+      if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, false)) return rc;
+    }
+  }
 
   auto collect_and_rank = [&](unsigned *n_acc) -> int {
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned), s));

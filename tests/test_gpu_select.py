@@ -229,3 +229,40 @@ def test_select_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case):
     refu = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, 40, grid=(32, 32),
                               capacity=4096)
     _same_lists(gotu, refu)
+
+
+@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 3), (0, 64), (1, 3)])
+@pytest.mark.parametrize("case,grid", [("texture", (32, 32)), ("texture", (20, 20)), ("texture", (9, 9)),
+                                       ("texture", (5, 7)), ("texture", (100, 90)),
+                                       ("big_scores", (32, 32)), ("flat_ties", (32, 32)), ("flat_ties", (20, 24))])
+def test_uniform_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case, grid):
+    """Phase A of the Uniform selector on 32-bit keys (dense cell rank | 26-bit score; select impl 0)
+    and on 64-bit keys (impl 1): the oracle's lists either way.  big_scores: scores of 2^26 and more
+    do not fit the 32-bit keys, the phase is repeated on 64-bit keys; grids (9, 9) / (5, 7): a haloed
+    tile meets more than 32 cells, 64-bit keys from the start; flat_ties: equal scores everywhere,
+    so the cell order and, inside a cell, raster order decide."""
+    H, W, n = 150, 260, 40
+    kw = dict(window=7, levels=2, border=8, mindist=10, min_eigenvalue=50)
+    if case == "texture":
+        _, sums = _sums(klt, ok, gpu_ctx, _frame(H, W))
+    else:
+        rng = np.random.default_rng(5)
+        if case == "big_scores":
+            amp = rng.uniform(2.0, 40.0, (H, W)).astype(np.float32)
+            amp[40:110, 60:200] = rng.uniform(2000.0, 9000.0, (70, 140)).astype(np.float32)  # lambda ~ 24 amp^2 up to 2e9
+        else:
+            amp = np.float32(8.0)
+        sums = ok.integral_products(*_checker_gradients(H, W, amp))
+    gpu_ctx.set_params(klt.make_params(**kw))
+    cap = 100 * n
+    ref = ok.select_features(ok.make_params(**kw), ok.SELECT_ALL, ok.VARIANT_UNIFORM, *sums, n, grid=grid, capacity=cap)
+    gpu_ctx.set_select_impl(impl)
+    gpu_ctx.set_select_iters(iters)
+    try:
+        got = klt.select_features(gpu_ctx, klt.SELECT_ALL, klt.VARIANT_UNIFORM, *sums, n, grid=grid, capacity=cap)
+    finally:
+        gpu_ctx.set_select_impl(0)
+        gpu_ctx.set_select_iters(3)
+    _same_lists(got, ref)
+    if case == "big_scores":
+        assert (ref[2] >= (1 << 26)).any()
