@@ -267,8 +267,12 @@ def algorithmic_bytes(cfg):
     return b_pyr, foot, px
 
 
-def cpu_baseline(params_kw, frames, seeds, nframes, threads):
-    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload."""
+CPU_SAMPLE_SECONDS = 12.0  # the cpu_baseline legs run about this long (bounded: 10-30 s of CPU work)
+
+
+def cpu_baseline(params_kw, frames, seeds, nframes, threads, seconds=CPU_SAMPLE_SECONDS):
+    """The CPU restatement (oracle/, kind 'port') on a bounded sample of the same workload: at
+    least `nframes` frames, then on until `seconds` of wall time have gone.  -> (rate, wall, frames)"""
     from oracle import oracle as ok
 
     ok.build()
@@ -277,8 +281,9 @@ def cpu_baseline(params_kw, frames, seeds, nframes, threads):
     x, y, val = (a.copy() for a in seeds)
     prev = ok.compute_pyramid(op, frames[0])
     t0 = time.perf_counter()
-    tracked = 0
-    for t in range(1, nframes + 1):
+    tracked, t = 0, 0
+    while t < nframes or time.perf_counter() - t0 < seconds:
+        t += 1
         if t % RESEED_EVERY == 0:
             x, y, val = (a.copy() for a in seeds)
         cur = ok.compute_pyramid(op, frames[t % len(frames)])
@@ -287,7 +292,7 @@ def cpu_baseline(params_kw, frames, seeds, nframes, threads):
         prev = cur
     dt = time.perf_counter() - t0
     ok.set_threads(1)
-    return tracked / dt, dt
+    return tracked / dt, dt, t
 
 
 def latency_leg(st, n):
@@ -526,7 +531,7 @@ def c5_params(cfg):
     return kw, sel
 
 
-def cpu_baseline_c5(cfg, frames, nframes, threads, variant):
+def cpu_baseline_c5(cfg, frames, nframes, threads, variant, seconds=CPU_SAMPLE_SECONDS):
     """C5 on the CPU restatement: pyramid, integral images, selection, track -- per frame."""
     from oracle import oracle as ok
 
@@ -538,17 +543,20 @@ def cpu_baseline_c5(cfg, frames, nframes, threads, variant):
     n = cfg["n"]
     cur = ok.compute_pyramid(op, frames[0])
     t0 = time.perf_counter()
-    tracked = 0
-    for t in range(nframes):
+    tracked, t = 0, 0
+    x = y = val = None
+    while t < nframes or time.perf_counter() - t0 < seconds:
         nxt = ok.compute_pyramid(op, frames[(t + 1) % len(frames)])
         sums = ok.integral_products(cur[1], cur[2])
-        x, y, val = ok.select_features(op, 0, variant, *sums, n, grid=sel["grid"])
+        # the list keeps the size the previous selection grew it to, as the device list does
+        x, y, val = ok.select_features(op, 0, variant, *sums, n if val is None else len(val), grid=sel["grid"])
         val = ok.track_features(op, cur, nxt, x, y, val)[2]
         tracked += int((val == 0).sum())
         cur = nxt
+        t += 1
     dt = time.perf_counter() - t0
     ok.set_threads(1)
-    return tracked / dt, dt
+    return tracked / dt, dt, t
 
 
 def main_c5(a, ctx, cfg, dist, rank, world):
@@ -670,8 +678,8 @@ def main_c5(a, ctx, cfg, dist, rank, world):
     }
     if rank == 0 and world == 1 and not a.no_cpu:
         threads = min(16, len(os.sched_getaffinity(0)))
-        ncpu = a.cpu_frames or 24
-        v, cdt = cpu_baseline_c5(cfg, frames, ncpu, threads, variant)
+        v, cdt, ncpu = cpu_baseline_c5(cfg, frames, a.cpu_frames or 4, threads, variant,
+                                       0.0 if a.cpu_frames else CPU_SAMPLE_SECONDS)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads, "kind": "port",
                                "sample": "%d frames of the same stream (pyramid + integral images + selection + "
                                          "track), oracle/ C restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
@@ -906,14 +914,14 @@ def main(argv=None):
 
     if rank == 0 and world == 1 and not a.no_cpu:
         threads = min(16, len(os.sched_getaffinity(0)))
-        ncpu = a.cpu_frames or {"C2": 160, "Cship": 160, "C3": 48}.get(a.config, 24)
-        v, cdt = cpu_baseline(params_kw, frames, seeds, ncpu, threads)
-        v1, cdt1 = cpu_baseline(params_kw, frames, seeds, max(ncpu // 16, 4), 1)
+        secs = CPU_SAMPLE_SECONDS if not a.cpu_frames else 0.0
+        v, cdt, nf = cpu_baseline(params_kw, frames, seeds, a.cpu_frames or 8, threads, secs)
+        v1, cdt1, nf1 = cpu_baseline(params_kw, frames, seeds, max((a.cpu_frames or 8) // 16, 2), 1, secs / 2)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads,
                                "kind": "port",
-                               "one_core": {"value": v1, "sample": "%d frames, %.1f s wall" % (max(ncpu // 16, 4), cdt1)},
+                               "one_core": {"value": v1, "sample": "%d frames, %.1f s wall" % (nf1, cdt1)},
                                "sample": "%d frames of the same stream (pyramid + track), oracle/ C "
-                                         "restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
+                                         "restatement with OpenMP, %.1f s wall" % (nf, cdt)}
     st.close()
     ctx.close()
     if rank == 0:

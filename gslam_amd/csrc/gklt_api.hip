@@ -286,7 +286,7 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
       GKLT_HIP(hipMalloc(&ctx->d_frame, bytes));
       ctx->d_frame_bytes = bytes;
     }
-    GKLT_HIP(hipMemcpy2DAsync(ctx->d_frame, W, img, stride, W, H, hipMemcpyHostToDevice, s));
+    GKLT_HIP(copy_plane_h2d(ctx->d_frame, img, stride, W, H, s));
     src = ctx->d_frame;
     src_stride = W;
   }

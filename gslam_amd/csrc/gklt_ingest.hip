@@ -107,10 +107,10 @@ int ingest(gklt_ctx *ctx, gklt_frame *f, const uint8_t *y, int ys, const uint8_t
     f->luma = y; f->luma_stride = ys;
     f->chroma = uv; f->chroma_stride = uvs;
   } else {
-    GKLT_HIP(hipMemcpy2DAsync(f->d_y, W, y, ys, W, H, hipMemcpyHostToDevice, s));
+    GKLT_HIP(copy_plane_h2d(f->d_y, y, ys, W, H, s));
     f->luma = f->d_y; f->luma_stride = W;
     if (uv) {
-      GKLT_HIP(hipMemcpy2DAsync(f->d_uv, W, uv, uvs, W, H / 2, hipMemcpyHostToDevice, s));
+      GKLT_HIP(copy_plane_h2d(f->d_uv, uv, uvs, W, H / 2, s));
       f->chroma = f->d_uv; f->chroma_stride = W;
     }
   }

@@ -119,8 +119,7 @@ static int enqueue_batch_build(gklt_lookahead *p, long first, const uint8_t *con
         set_error("out of device memory for the frame staging buffer");
         return GKLT_ENOMEM;
       }
-      GKLT_HIP(hipMemcpy2DAsync(p->stage[i], p->W, frames[i], stride, p->W, p->H,
-                                hipMemcpyHostToDevice, p->sp));
+      GKLT_HIP(copy_plane_h2d(p->stage[i], frames[i], stride, p->W, p->H, p->sp));
       src[i] = p->stage[i];
     }
   }

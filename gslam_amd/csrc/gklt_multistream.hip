@@ -144,8 +144,7 @@ static int enqueue_builds(gklt_multistream *m, long frame, const uint8_t *const 
           set_error("out of device memory for the frame staging buffers");
           return GKLT_ENOMEM;
         }
-        GKLT_HIP(hipMemcpy2DAsync(m->stage[s], m->W, imgs[s], stride, m->W, m->H,
-                                  hipMemcpyHostToDevice, m->sp));
+        GKLT_HIP(copy_plane_h2d(m->stage[s], imgs[s], stride, m->W, m->H, m->sp));
         src[i] = m->stage[s];
       }
     }

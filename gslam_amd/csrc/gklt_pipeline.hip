@@ -48,7 +48,7 @@ static int enqueue_frame_build(gklt_pipeline *p, long frame, const uint8_t *img,
   const uint8_t *src = img;
   int src_stride = stride;
   if (!on_device) {
-    GKLT_HIP(hipMemcpy2DAsync(p->d_stage[si], p->W, img, stride, p->W, p->H, hipMemcpyHostToDevice, s));
+    GKLT_HIP(copy_plane_h2d(p->d_stage[si], img, stride, p->W, p->H, s));
     src = p->d_stage[si];
     src_stride = p->W;
   }
