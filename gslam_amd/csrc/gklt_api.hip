@@ -839,7 +839,8 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
 
 // 0 = one feature per wavefront, LDS footprint staging chosen by window size (default);
 // 1 = one feature per 8-lane slice; 2 / 3 = one feature per wavefront with four gathers per
-// element / with LDS staging (0 picks footprint-in-registers, gathers or staging by window size)
+// element / with LDS staging and the element-per-lane mapping (0 picks footprint-in-registers,
+// gathers or staging by window size, and the row-run mapping where it stages)
 extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->track_impl = impl;

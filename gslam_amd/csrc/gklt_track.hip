@@ -17,6 +17,7 @@
 // Each bilinear tap is one 12-byte load of an (I,gx,gy) texel (layout written by
 // gklt_pyramid.hip).
 #include <algorithm>
+#include <cstdlib>
 
 #include "gklt_internal.h"
 
@@ -45,6 +46,8 @@ struct TrackArgs {
   // kernel itself (pinned host memory), so no D2H copy sits on the stream after the launch
   float *mirror;
   int mirror_stride;
+  int halo;     // k_track_w with staging: margin of the LDS footprint in texels
+  int fstride;  // ... and its row stride in LDS, texels (>= footprint width; bank spreading)
 };
 
 // Multi-frame launches (lookahead pipeline): a wavefront follows its feature through nframes
@@ -67,6 +70,10 @@ struct TrackStreams {
 };
 
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// words between the product arrays of k_track_w (see there): NA or NA + 8, an odd multiple of 8
+__host__ __device__ constexpr int prod_stride(int NA) { return (NA >> 3) & 1 ? NA : NA + 8; }
 constexpr int kStatShards = GKLT_STAT_SHARDS;
 
 struct Bilin {
@@ -409,7 +416,12 @@ __global__ __launch_bounds__(64) void k_track(TrackArgs a, float *__restrict__ f
 // The texture path then sees a quarter of the lane-addresses and about a sixth of the cache
 // accesses.  Window element (r, c) sits in lane r*(w+1)+c and keeps its row-major index r*w+c
 // for the ordered reductions.
-template <int EPL, int FPL, int NEC = 0, bool MS = false, bool FRM = false>
+// RUN > 0 (staged windows 15..21 px wide): lane l owns the RUN consecutive elements
+// (r, c0 .. c0 + RUN - 1) of ONE window row, r = l / S, c0 = (l % S) * RUN, S = ceil(w / RUN),
+// instead of elements l, l + 64, ...  Its 2 (RUN + 1) footprint texels are then read from LDS once
+// per pass at constant offsets from one address (4 RUN reads and RUN addresses otherwise), and
+// its products go to consecutive words.  Which lane computes an element does not enter a result.
+template <int EPL, int FPL, int NEC = 0, bool MS = false, bool FRM = false, int RUN = 0>
 __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, TrackStreams M,
                                                 float *__restrict__ fx,
                                                 float *__restrict__ fy, int *__restrict__ fval,
@@ -417,7 +429,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
                                                 double *__restrict__ norm3,
                                                 double *__restrict__ vec3,
                                                 unsigned long long *__restrict__ stats) {
-  extern __shared__ __align__(16) float lds[];  // prod[5][NA] | part[40] | fp[NF] (float4)
+  extern __shared__ __align__(16) float lds[];  // prod[5][NAs] | part[40] | fp[NF + 8] (float4)
+  constexpr int NT = 64;
   const int lane = threadIdx.x;
   const int ww = a.ww, wh = a.wh, npix = ww * wh;
   const int NA = SL * ((npix + SL) / SL);  // alignedPatchSize (LK.hpp:448)
@@ -425,10 +438,20 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   const int hw = ww / 2, hh = wh / 2;
   constexpr bool STAGE = FPL > 0;
   constexpr int FP = STAGE ? FPL : 1;
+  // The five chains of a reduction read prod[q][k + 8u] together (lanes 8q + k): the stride between
+  // quantities is an odd multiple of 8 words, so that the 40 lanes fall into 40 different banks
+  // (NA itself is a multiple of 64 for 11x11 and 21x21 windows: a five-way conflict on every read).
+  const int NAs = prod_stride(NA);
   float *prod = lds;
-  float *part = lds + 5 * NA;
+  float *part = lds + 5 * NAs;
   float4 *fp = reinterpret_cast<float4 *>(part + 40);
-  const int FW = ww + 1, NF = FW * (wh + 1);
+  // Staged footprint: (w + 1 + 2 HL) x (h + 1 + 2 HL) texels around the window's origin.  The HL
+  // extra texels on every side let the Newton iterations that move the window by less than HL
+  // whole pixels -- nearly all but the first of a level -- sample from the texels already in LDS:
+  // an iteration then costs no trip to memory.  Same texels, same weights, same sums.
+  const int HL = STAGE ? a.halo : 0;
+  const int FW = ww + 1 + 2 * HL, NF = FW * (wh + 1 + 2 * HL);
+  const int FS = STAGE ? a.fstride : FW;  // footprint texel (x, y) sits at fp[y * FS + x]
 
   // element -> texel offset inside the window (tail elements clamp to the last pixel, value 0)
   // and -> index of its products in prod[] (-1: none)
@@ -445,10 +468,27 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     const unsigned long long spare = __ballot(!evalid[0]);
     const int rank = __popcll(spare & ((1ull << lane) - 1ull));
     pidx[0] = evalid[0] ? eoff_y[0] * ww + eoff_x[0] : (rank < NA - npix ? npix + rank : -1);
+  } else if constexpr (RUN > 0) {
+    static_assert(EPL == RUN && FPL > 0, "row-run mapping samples from the staged footprint");
+    const int S = (ww + RUN - 1) / RUN;
+    const int r = lane / S, c0 = (lane - r * S) * RUN;
+    const int rc = min(r, wh - 1);  // lanes past the last row read (and discard) its texels
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      eoff_y[e] = rc;
+      eoff_x[e] = c0 + e;  // up to RUN - 1 texels past the row's end: fp[] is padded for it
+      evalid[e] = r < wh && c0 + e < ww;
+      pidx[e] = evalid[e] ? rc * ww + c0 + e : -1;
+    }
+    // nobody owns the zero tail npix..NA-1 of the padded patch: written once
+    if (lane < NA - npix) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) prod[q * NAs + npix + lane] = 0.f;
+    }
   } else {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
-      const int i = e * 64 + lane;
+      const int i = e * NT + lane;
       const int ic = min(i, npix - 1);
       eoff_y[e] = ic / ww;
       eoff_x[e] = ic - eoff_y[e] * ww;
@@ -481,35 +521,58 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       return sample_i(p, nc, b);
     }
   };
-  // footprint texel j = e*64 + lane -> offset inside the footprint (clamped past the end)
+  // footprint texel j = e*NT + lane -> offset inside the footprint (clamped past the end)
   int foff_x[FP], foff_y[FP];
   if (STAGE) {
 #pragma unroll
     for (int e = 0; e < FP; ++e) {
-      const int jc = min(e * 64 + lane, NF - 1);
+      const int jc = min(e * NT + lane, NF - 1);
       foff_y[e] = jc / FW;
       foff_x[e] = jc - foff_y[e] * FW;
     }
   }
-  auto fp_load = [&](const Texel *o, int nc, float3 (&t)[FP]) {
+  // footprint whose first texel is (X0, Y0); texels of the margin that fall outside the plane are
+  // clamped into it (never sampled: a window that would reach them is out of bounds first)
+  // X0, Y0 are the same in every lane; telling the compiler so (readfirstlane) moves the address
+  // arithmetic of the common case -- footprint inside the plane -- to the scalar unit: one base
+  // address plus a per-lane offset per texel.
+  auto fp_load = [&](const Texel *plane, int nc, int nr, int X0v, int Y0v, float3 (&t)[FP]) {
+    const int X0 = __builtin_amdgcn_readfirstlane(X0v), Y0 = __builtin_amdgcn_readfirstlane(Y0v);
+    if (X0 >= 0 && Y0 >= 0 && X0 + FW <= nc && Y0 + (NF / FW) <= nr) {
+      const Texel *o = plane + ((size_t)Y0 * nc + X0);
 #pragma unroll
-    for (int e = 0; e < FP; ++e) {
-      const Texel v = o[foff_y[e] * nc + foff_x[e]];
-      t[e] = make_float3(v.x, v.y, v.z);
+      for (int e = 0; e < FP; ++e) {
+        const Texel v = o[(unsigned)(foff_y[e] * nc + foff_x[e])];
+        t[e] = make_float3(v.x, v.y, v.z);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < FP; ++e) {
+        const int tx = min(max(X0 + foff_x[e], 0), nc - 1), ty = min(max(Y0 + foff_y[e], 0), nr - 1);
+        const Texel v = plane[(size_t)ty * nc + tx];
+        t[e] = make_float3(v.x, v.y, v.z);
+      }
     }
   };
+  // LDS texel: (gx, gy, I, -) -- the gradient pair sits in an even-aligned register pair after the
+  // 16-byte read, which is what the packed fp32 instructions take
   auto fp_store = [&](const float3 (&t)[FP]) {
 #pragma unroll
     for (int e = 0; e < FP; ++e)
-      if (e * 64 + lane < NF) fp[e * 64 + lane] = make_float4(t[e].x, t[e].y, t[e].z, 0.f);
+      if (e * NT + lane < NF) fp[foff_y[e] * FS + foff_x[e]] = make_float4(t[e].y, t[e].z, t[e].x, 0.f);
   };
-  auto fp_sample = [&](int e, const Bilin &b) {
-    const float4 *q = fp + eoff_y[e] * FW + eoff_x[e];
-    const float4 t00 = q[0], t01 = q[1], t10 = q[FW], t11 = q[FW + 1];
+  // element e of the window whose origin sits (ox, oy) texels inside the staged footprint
+  auto fp_sample = [&](int e, const Bilin &b, int ox, int oy) {
+    const float4 *q = fp + (eoff_y[e] + oy) * FS + (eoff_x[e] + ox);
+    const float4 t00 = q[0], t01 = q[1], t10 = q[FS], t11 = q[FS + 1];
+    // both gradients in one packed multiply / add each (v_pk_mul_f32, v_pk_add_f32: two
+    // independent IEEE operations, the same roundings as the scalar expression)
+    const f32x2 g = (f32x2{t00.x, t00.y} * b.w0 + f32x2{t01.x, t01.y} * b.w1) +
+                    (f32x2{t10.x, t10.y} * b.w2 + f32x2{t11.x, t11.y} * b.w3);
     float3 o;
-    o.x = (t00.x * b.w0 + t01.x * b.w1) + (t10.x * b.w2 + t11.x * b.w3);
-    o.y = (t00.y * b.w0 + t01.y * b.w1) + (t10.y * b.w2 + t11.y * b.w3);
-    o.z = (t00.z * b.w0 + t01.z * b.w1) + (t10.z * b.w2 + t11.z * b.w3);
+    o.x = (t00.z * b.w0 + t01.z * b.w1) + (t10.z * b.w2 + t11.z * b.w3);
+    o.y = g.x;
+    o.z = g.y;
     return o;
   };
   // ordered reduction of nq quantities whose per-element products sit in prod[q][0..NA)
@@ -518,8 +581,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     float acc = 0.f;
     if (lane < nq * SL) {
       const int q = lane >> 3, k = lane & 7;
-      const float *p = prod + q * NA + k;
-      if constexpr (NEC > 0 && NEC <= 16) {
+      const float *p = prod + q * NAs + k;
+      if constexpr (NEC > 0 && NEC <= 64) {
         float t[NEC];
 #pragma unroll
         for (int u = 0; u < NEC; ++u) t[u] = p[u * SL];
@@ -636,20 +699,35 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       clamp_origin(b2, hw, hh, nc, nr);
       const Texel *o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
       float3 T1[EPL], S2[EPL];
+      int X0 = 0, Y0 = 0;  // first texel of the second image's footprint in LDS
+      // stages the footprint around window origin (wx, wy) unless the one in LDS covers it;
+      // returns the origin's offset inside the footprint
+      auto stage2 = [&](int wx, int wy, int &ox, int &oy) {
+        ox = wx - X0; oy = wy - Y0;
+        if (ox >= 0 && ox <= 2 * HL && oy >= 0 && oy <= 2 * HL) return;
+        float3 f2[FP];
+        X0 = wx - HL; Y0 = wy - HL;
+        fp_load(lt2, nc, nr, X0, Y0, f2);
+        __syncthreads();  // previous readers of fp are done
+        fp_store(f2);
+        __syncthreads();
+        ox = HL; oy = HL;
+      };
       if (STAGE) {
         float3 f1[FP], f2[FP];
-        fp_load(o1, nc, f1);  // both footprints are in flight together
-        fp_load(o2, nc, f2);
+        X0 = b2.xt - hw - HL; Y0 = b2.yt - hh - HL;
+        fp_load(lt1, nc, nr, b1.xt - hw - HL, b1.yt - hh - HL, f1);  // both footprints are in flight together
+        fp_load(lt2, nc, nr, X0, Y0, f2);
         __syncthreads();      // previous readers of fp are done
         fp_store(f1);
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) T1[e] = fp_sample(e, b1);
+        for (int e = 0; e < EPL; ++e) T1[e] = fp_sample(e, b1, HL, HL);
         __syncthreads();
         fp_store(f2);
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
+        for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2, HL, HL);
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) T1[e] = gather3(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
@@ -670,11 +748,11 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           const float gx = T1[e].y + s.y;    // computeImageSum  :118-125
           const float gy = T1[e].z + s.z;
           if (i >= 0) {
-            prod[0 * NA + i] = gx * gx;      // compute2X2GradientMatrix :127-146
-            prod[1 * NA + i] = gy * gy;
-            prod[2 * NA + i] = gx * gy;
-            prod[3 * NA + i] = gx * diff;    // compute2X1ErrorVector :148-166
-            prod[4 * NA + i] = gy * diff;
+            prod[0 * NAs + i] = gx * gx;      // compute2X2GradientMatrix :127-146
+            prod[1 * NAs + i] = gy * gy;
+            prod[2 * NAs + i] = gx * gy;
+            prod[3 * NAs + i] = gx * diff;    // compute2X1ErrorVector :148-166
+            prod[4 * NAs + i] = gy * diff;
           }
         }
         float tot[5];
@@ -696,13 +774,10 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         clamp_origin(b2, hw, hh, nc, nr);
         o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         if (STAGE) {
-          float3 f2[FP];
-          fp_load(o2, nc, f2);
-          __syncthreads();
-          fp_store(f2);
-          __syncthreads();
+          int ox, oy;
+          stage2(b2.xt - hw, b2.yt - hh, ox, oy);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2);
+          for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2, ox, oy);
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) S2[e] = gather3(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
@@ -718,13 +793,10 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
         float sI[EPL];
         if (STAGE) {
-          float3 f2[FP];
-          fp_load(o2, nc, f2);
-          __syncthreads();
-          fp_store(f2);
-          __syncthreads();
+          int ox, oy;
+          stage2(b2.xt - hw, b2.yt - hh, ox, oy);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) sI[e] = fp_sample(e, b2).x;
+          for (int e = 0; e < EPL; ++e) sI[e] = fp_sample(e, b2, ox, oy).x;
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sI[e] = gather1(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
@@ -840,21 +912,72 @@ void fill_args(const gklt_params &P, const gklt_pyramid *py0, int n, bool epilog
 }
 
 struct WaveGeom {
-  int NA, NF, epl, fpl;
+  int NA, NF, epl, fpl, run, halo, fstride;
   bool stage, fits, frm;
   size_t lds;
 };
 
+WaveGeom wave_geom_compute(const gklt_ctx *ctx, int ww, int wh);
+
+// (the stride search below is a few hundred microseconds of host time: once per window and mapping)
 WaveGeom wave_geom(const gklt_ctx *ctx, int ww, int wh) {
+  struct Key { int ww, wh, impl; WaveGeom g; };
+  static thread_local Key last{-1, -1, -1, {}};
+  if (last.ww != ww || last.wh != wh || last.impl != ctx->track_impl)
+    last = Key{ww, wh, ctx->track_impl, wave_geom_compute(ctx, ww, wh)};
+  return last.g;
+}
+
+WaveGeom wave_geom_compute(const gklt_ctx *ctx, int ww, int wh) {
   WaveGeom g;
   g.NA = 8 * ((ww * wh + 8) / 8);
+  g.halo = g.run = 0;
   g.NF = (ww + 1) * (wh + 1);
   // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
   // 19.2 us at C2, 11x11 86 / 98 us at C3, 21x21 67 / 39 us at Cship); track_impl 2 / 3 force it.
   g.stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && ww * wh >= 200);
-  g.epl = (g.NA + 63) / 64;
+  if (g.stage) {
+    static const int env_halo = getenv("GKLT_TRACK_HALO") ? atoi(getenv("GKLT_TRACK_HALO")) : 0;
+    g.halo = std::min(std::max(env_halo, 0), 4);
+    g.NF = (ww + 1 + 2 * g.halo) * (wh + 1 + 2 * g.halo);
+  }
+  // row-run mapping (k_track_w, RUN = 7): three runs of seven cover a row of 15..21 elements and
+  // 3 * wh lanes must exist; track_impl 3 keeps the element-per-lane mapping for A/B runs
+  g.run = g.stage && ctx->track_impl == 0 && ww >= 15 && ww <= 21 && 3 * wh <= 64 ? 7 : 0;
+  // LDS row stride of the footprint.  With the row-run mapping lane l reads 16 bytes at texel
+  // (l / 3 + dy) * stride + (l % 3) * 7 + e: the stride decides how the lanes spread over the
+  // banks (width 24 -> two rows apart is 3 * 64 words: the same banks; 29 spreads them).  Chosen by
+  // counting the bank passes of the 16 reads of a pass under a 16-lane, 32- and 64-bank model.
+  g.fstride = ww + 1 + 2 * g.halo;
+  if (g.run) {
+    auto passes = [&](int fs, int nbanks) {
+      int tot = 0;
+      for (int dy = 0; dy < 2; ++dy)
+        for (int e = 0; e <= g.run; ++e)
+          for (int g0 = 0; g0 < 64; g0 += 16) {
+            int cnt[64] = {0}, worst = 0;
+            for (int l = g0; l < g0 + 16; ++l) {
+              const int r = std::min(l / 3, wh - 1), c0 = (l % 3) * g.run;
+              const int a0 = ((r + dy) * fs + c0 + e) * 4;
+              bool dup = false;  // same texel as an earlier lane of the group: one access
+              for (int m = g0; m < l; ++m)
+                dup |= std::min(m / 3, wh - 1) == r && (m % 3) * g.run == c0;
+              if (dup) continue;
+              for (int w = 0; w < 4; ++w) worst = std::max(worst, ++cnt[(a0 + w) % nbanks]);
+            }
+            tot += worst;
+          }
+      return tot;
+    };
+    int best = 1 << 30;
+    for (int fs = ww + 1 + 2 * g.halo; fs <= ww + 1 + 2 * g.halo + 8; ++fs) {
+      const int c = passes(fs, 32) + passes(fs, 64);
+      if (c < best) { best = c; g.fstride = fs; }
+    }
+  }
+  g.epl = g.run ? g.run : (g.NA + 63) / 64;
   g.fpl = (g.NF + 63) / 64;
-  g.lds = sizeof(float) * (size_t)(5 * g.NA + 40) + (g.stage ? sizeof(float4) * (size_t)g.NF : 0);
+  g.lds = sizeof(float) * (size_t)(5 * prod_stride(g.NA) + 40) + (g.stage ? sizeof(float4) * (size_t)(g.fstride * (wh + 1 + 2 * g.halo) + 8) : 0);
   g.fits = g.epl <= 16 && g.fpl <= 16 && g.lds <= 48 * 1024;
   // footprint-in-registers sampling: the whole (w+1)(h+1) footprint in one wavefront
   // (track_impl 2 keeps the four gathers per element for A/B runs)
@@ -870,6 +993,9 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
   const dim3 block(64);
   const size_t wlds = g.lds;
   const int epl = g.epl, fpl = g.fpl;
+#define GKLT_TRACK_RUN7(FP, NE)                                                                  \
+  hipLaunchKernelGGL((k_track_w<7, FP, NE, MS, false, 7>), dim3(nwaves), block, wlds, s, a, F, M, \
+                     x, y, val, d_invk, d_norm, d_vec, stats)
 #define GKLT_TRACK_W(E, FP, NE)                                                                 \
   hipLaunchKernelGGL((k_track_w<E, FP, NE, MS>), dim3(nwaves), block, wlds, s, a, F, M, x, y, val, \
                      d_invk, d_norm, d_vec, stats)
@@ -877,7 +1003,11 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
   hipLaunchKernelGGL((k_track_w<1, 0, NE, MS, true>), dim3(nwaves), block, wlds, s, a, F, M, x, y, \
                      val, d_invk, d_norm, d_vec, stats)
   const int nec = g.NA / 8;
-  if (!g.stage) {
+  if (g.run == 7) {
+    if (nec == 56 && fpl <= 9) GKLT_TRACK_RUN7(9, 56);  // 21x21
+    else if (fpl <= 9) GKLT_TRACK_RUN7(9, 0);
+    else GKLT_TRACK_RUN7(13, 0);  // margins up to 4
+  } else if (!g.stage) {
     if (g.frm && nec == 7) GKLT_TRACK_FRM(7);  // 7x7, footprint in registers
     else if (g.frm) GKLT_TRACK_FRM(0);
     else if (epl <= 1 && nec == 7) GKLT_TRACK_W(1, 0, 7);  // 7x7
@@ -887,6 +1017,8 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
     else if (epl <= 4) GKLT_TRACK_W(4, 0, 0);
     else if (epl <= 8) GKLT_TRACK_W(8, 0, 0);
     else GKLT_TRACK_W(16, 0, 0);
+  } else if (epl <= 7 && fpl <= 9 && nec == 56) {
+    GKLT_TRACK_W(7, 9, 56);  // 21x21
   } else if (epl <= 1) {
     if (fpl <= 1) GKLT_TRACK_W(1, 1, 0); else GKLT_TRACK_W(1, 2, 0);
   } else if (epl <= 2) {
@@ -899,6 +1031,7 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
     GKLT_TRACK_W(16, 16, 0);
   }
 #undef GKLT_TRACK_W
+#undef GKLT_TRACK_RUN7
 #undef GKLT_TRACK_FRM
 }
 
@@ -940,6 +1073,8 @@ int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, 
   if (total <= 0) return 0;
   TrackArgs a;
   fill_args(P, py0, M.nmax, false, mirror_stride, &a);
+  a.halo = g.halo;
+  a.fstride = g.fstride;
   TrackFrames F{};
   F.nframes = 1;
   F.mirror[0] = mirror;
@@ -979,6 +1114,8 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
   if (n <= 0) return 0;
 
   const WaveGeom g = wave_geom(ctx, a.ww, a.wh);
+  a.halo = g.halo;
+  a.fstride = g.fstride;
   const dim3 block(64);
 
   if (ctx->track_impl != 1 && g.fits) {  // feature per wave

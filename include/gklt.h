@@ -424,7 +424,8 @@ int gklt_device_synchronize(gklt_ctx *ctx);
 
 /* Tracker mapping: 0 = one feature per wavefront; sampling chosen by window size: footprint in
  * registers (footprint <= 64 texels, e.g. 7x7), four gathers per element, or LDS footprint staging
- * (default); 1 = one feature per 8-lane slice; 2 / 3 = per wavefront with gathers / with staging.
+ * with a lane per window-row run (default); 1 = one feature per 8-lane slice; 2 / 3 = per wavefront
+ * with gathers / with staging and a lane per element.
  * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
 /* Wavefronts per wave-per-feature tracker launch; each takes features w, w + waves, ...  The

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gslam_amd import klt, synth
 
+IMPLS = tuple(int(v) for v in os.environ.get('IMPLS', '0,2,3,1').split(','))
 for name in sys.argv[1:] or ["C2", "C3", "Cship"]:
     cfg = synth.CONFIGS[name]; H, W, n = cfg["H"], cfg["W"], cfg["n"]
     gp = klt.make_params(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
@@ -16,7 +17,7 @@ for name in sys.argv[1:] or ["C2", "C3", "Cship"]:
     x, y = synth.lattice_seeds(H, W, n, gp.borderx, nx=cfg["lattice"][0], ny=cfg["lattice"][1])
     v = np.zeros(n, np.int32)
     fl = klt.FeatureList(ctx, n)
-    for impl in (0, 2, 3, 1):
+    for impl in IMPLS:
         ctx.set_track_impl(impl)
         for rep in range(3):
             fl.upload(x, y, v)
