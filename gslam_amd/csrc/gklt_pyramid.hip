@@ -1,6 +1,14 @@
-// Pyramid kernels for gfx950: separable Gaussian smoothing, smoothing + 2x decimation, and
-// Gaussian-derivative gradients.  Each launch stages a haloed tile in LDS, runs the row pass
-// LDS -> LDS and the column pass LDS -> HBM.
+// Pyramid kernels for gfx950.  Two families in this file:
+//  * k_level<SrcT, R0, RP, RG, DOWN, NTHREADS> (the default path): ONE launch per pyramid level
+//    that fuses smoothing, both gradient passes, texel packing and the 2x decimation for the next
+//    level; 64 x 32 output tile per workgroup of 4 or 8 wavefronts, register-blocked passes
+//    through LDS, blockIdx.z = frame (lookahead) or stream (multi-stream).  DESIGN.md 4.1.
+//    (gklt_pyramid_stream.hip holds a second, barrier-free form of the same kernel: one
+//    wavefront per column strip, selectable with gklt_ctx_set_pyramid_impl(ctx, 3).)
+//  * k_smooth_fast / k_grad_fast / k_smooth / k_grad (pyramid impl 1, the standalone gklt_smooth /
+//    gklt_gradients entry points, and every configuration the fused kernel is not instantiated
+//    for): separable Gaussian with optional 2x decimation, and gradients + texel packing, each
+//    staging a haloed tile in LDS, row pass LDS -> LDS, column pass LDS -> HBM.
 //
 // Replaces cv::sepFilter2D / cv::resize as called from pyramid.cpp:45-84 and convolve.cpp:19-56.
 // Arithmetic is fp32 with every product and sum rounded separately (the translation unit is
@@ -10,11 +18,11 @@
 // with BORDER_REFLECT_101 on the source index, which is the order the test oracle uses, so the
 // planes can be compared bit for bit.
 //
-// Tile = 64 x 16 outputs per 256-thread block: a wavefront owns whole tile rows (lane = column),
-// so LDS rows are read and written conflict-free and HBM rows are 256-byte (fp32) or 1 KiB
-// (texel) contiguous stores.  Kernel radii are template parameters for the radii the reference's
-// sigmas produce (taps live in SGPRs, loops fully unrolled); other radii take the R = 0
-// instantiation, which keeps the taps in LDS.
+// Separate kernels: tile = 64 x 16 outputs per 256-thread block (TW, TH below); a wavefront owns
+// whole tile rows (lane = column), so LDS rows are read and written conflict-free and HBM rows are
+// 256-byte (fp32) or 768-byte (12-byte texel) contiguous stores.  Kernel radii are template
+// parameters for the radii the reference's sigmas produce (taps live in SGPRs, loops fully
+// unrolled); other radii take the R = 0 instantiation, which keeps the taps in LDS.
 //
 // HBM layout written here: per level a planar fp32 image `img` (input of the
 // next level, downloads) and an interleaved texel array (I, gx, gy) that the tracker gathers

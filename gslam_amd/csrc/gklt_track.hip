@@ -1,11 +1,16 @@
 // Coarse-to-fine iterative Lucas-Kanade for gfx950 -- replaces KLTTrackFeatures / KLTInvoker /
 // _trackFeature and the AVX helpers under them (LK.hpp:56-208, 413-669, 825-1046).
 //
-// Two mappings, bit-identical to each other and to the oracle:
-//  * k_track_w (the default, second half of this file): ONE FEATURE PER WAVEFRONT, window
-//    element i -> lane i % 64, the reference's AVX summation order rebuilt through LDS chain
-//    sums; 7x7 windows hold the bilinear footprint in registers (one load per lane and patch),
-//    windows >= 15 px stage it in LDS.  Multi-frame (lookahead) and multi-stream launches.
+// Two kernels, bit-identical to each other and to the oracle:
+//  * k_track_w (the default, second half of this file): ONE FEATURE PER WAVEFRONT, the reference's
+//    AVX summation order rebuilt through LDS chain sums.  Sampling by window size:
+//      footprint (w+1)(h+1) <= 64 texels (7x7): footprint in registers, one load per lane and
+//        patch, neighbours through DPP / one shuffle (FRM);
+//      up to ~14 px: element i -> lane i % 64, four 12-byte gathers per element;
+//      >= 15 px (w*h >= 200): footprint staged in LDS once per pass; for windows 15..21 px wide
+//        a lane owns a run of 7 consecutive elements of one window row (RUN), otherwise
+//        element i -> lane i % 64.
+//    Multi-frame (lookahead) and multi-stream launches.
 //  * k_track (track_impl 1, and the fallback for windows the wave kernel cannot hold): one
 //    feature per 8-lane slice (8 features per wave64).  Lane k of a slice owns window elements
 //    k, k+8, k+16, ... in row-major window order -- exactly the elements AVX lane k accumulates
