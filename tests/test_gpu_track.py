@@ -82,6 +82,37 @@ def test_track_alternative_kernels_agree(klt, ok, gpu_ctx, window, levels, impl)
     _assert_same(got, ref)
 
 
+@pytest.mark.parametrize("ww,wh", [(15, 15), (17, 17), (19, 19), (21, 15), (15, 21), (19, 13), (17, 21), (23, 21), (21, 23)])
+def test_track_row_run_mapping_windows(klt, ok, gpu_ctx, ww, wh):
+    """Staged windows 15..21 px wide take the row-run mapping (a lane owns 7 consecutive elements of
+    one window row): widths that are not 3 x 7 leave partial runs, heights below 21 leave idle lanes,
+    23 px falls back to the element-per-lane mapping.  Features up to the border exercise the
+    footprint fetch at the image edge.  Exact against the oracle, 2 levels."""
+    H, W = 200, 320
+    f = _stream(H, W, 2, seed=5)
+    gp = klt.make_params(window=21, levels=2)
+    op = ok.make_params(window=21, levels=2)
+    for q in (gp, op):
+        q.window_width, q.window_height = ww, wh
+    gpu_ctx.set_params(gp)
+    rng = np.random.default_rng(ww * 100 + wh)
+    n = 257
+    x = rng.uniform(0, W - 1, n).astype(np.float32)     # anywhere, incl. inside the border strip
+    y = rng.uniform(0, H - 1, n).astype(np.float32)
+    x[:8] = [ww // 2, ww // 2 + 0.5, W - 1 - ww // 2, W - 1.5 - ww // 2, 100, 100, 2 * (ww // 2), W - 2 * (ww // 2) - 2]
+    y[:8] = [100, 100, 100, 100, wh // 2, H - 1 - wh // 2, 2 * (wh // 2), H - 2 * (wh // 2) - 2]
+    val = np.zeros(n, np.int32)
+    p0, p1 = klt.Pyramid(gpu_ctx, W, H), klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(f[0]); p1.build(f[1])
+        got = klt.KLTTrackFeatures(gpu_ctx, p0, p1, x, y, val)
+        ref = ok.track_features(op, p0.planes(), p1.planes(), x, y, val)
+    finally:
+        p0.close(); p1.close()
+    _assert_same(got, ref)
+    assert (got[2] == 0).sum() > n // 3
+
+
 def test_track_rectangular_window_and_even_fix(klt, ok, gpu_ctx):
     """Even / too-small windows are corrected (LK.hpp:982-1013): 6x2 becomes 7x3."""
     H, W = 135, 240
