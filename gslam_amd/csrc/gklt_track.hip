@@ -53,6 +53,9 @@ struct TrackArgs {
   int mirror_stride;
   int halo;     // k_track_w with staging: margin of the LDS footprint in texels
   int fstride;  // ... and its row stride in LDS, texels (>= footprint width; bank spreading)
+  // ceil(2^16 / d) for d = window width and footprint width: j / d == (j * magic) >> 16 for the
+  // j < 1024 the lane mappings divide (an integer division is ~30 VALU instructions on this part)
+  int ww_magic, fw_magic;
 };
 
 // Multi-frame launches (lookahead pipeline): a wavefront follows its feature through nframes
@@ -77,8 +80,9 @@ struct TrackStreams {
 constexpr int SL = 8;  // lanes per feature == simd_step of the reference (LK.hpp:40)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// words between the product arrays of k_track_w (see there): NA or NA + 8, an odd multiple of 8
-__host__ __device__ constexpr int prod_stride(int NA) { return (NA >> 3) & 1 ? NA : NA + 8; }
+// words between the product arrays of k_track_w (see there): NA + 8 or NA + 16, an odd multiple of 8
+// (always > NA: the gap takes the writes of lanes that own no element, see RUN)
+__host__ __device__ constexpr int prod_stride(int NA) { return (NA >> 3) & 1 ? NA + 16 : NA + 8; }
 constexpr int kStatShards = GKLT_STAT_SHARDS;
 
 struct Bilin {
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   // The five chains of a reduction read prod[q][k + 8u] together (lanes 8q + k): the stride between
   // quantities is an odd multiple of 8 words, so that the 40 lanes fall into 40 different banks
   // (NA itself is a multiple of 64 for 11x11 and 21x21 windows: a five-way conflict on every read).
-  const int NAs = prod_stride(NA);
+  const int NAs = NEC > 0 ? prod_stride(SL * NEC) : prod_stride(NA);
   float *prod = lds;
   float *part = lds + 5 * NAs;
   float4 *fp = reinterpret_cast<float4 *>(part + 40);
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
   if constexpr (FRM) {
     static_assert(EPL == 1 && FPL == 0, "one footprint texel per lane");
     const int jc = min(lane, NF - 1);
-    eoff_y[0] = jc / FW;
+    eoff_y[0] = (jc * a.fw_magic) >> 16;
     eoff_x[0] = jc - eoff_y[0] * FW;
     evalid[0] = lane < NF && eoff_y[0] < wh && eoff_x[0] < ww;
     // the zero tail npix..NA-1 of the padded patch is written by the first lanes that hold no
@@ -475,7 +479,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     pidx[0] = evalid[0] ? eoff_y[0] * ww + eoff_x[0] : (rank < NA - npix ? npix + rank : -1);
   } else if constexpr (RUN > 0) {
     static_assert(EPL == RUN && FPL > 0, "row-run mapping samples from the staged footprint");
-    const int S = (ww + RUN - 1) / RUN;
+    static_assert(RUN == 7, "three runs per row: windows 15..21 wide (wave_geom)");
+    constexpr int S = 3;
     const int r = lane / S, c0 = (lane - r * S) * RUN;
     const int rc = min(r, wh - 1);  // lanes past the last row read (and discard) its texels
 #pragma unroll
@@ -483,7 +488,9 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       eoff_y[e] = rc;
       eoff_x[e] = c0 + e;  // up to RUN - 1 texels past the row's end: fp[] is padded for it
       evalid[e] = r < wh && c0 + e < ww;
-      pidx[e] = evalid[e] ? rc * ww + c0 + e : -1;
+      // products of elements nobody owns go to the gap behind each array (NA + e < NAs): the
+      // writes of a pass are then unconditional and share one address register per element
+      pidx[e] = evalid[e] ? rc * ww + c0 + e : NA + e;
     }
     // nobody owns the zero tail npix..NA-1 of the padded patch: written once
     if (lane < NA - npix) {
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     for (int e = 0; e < EPL; ++e) {
       const int i = e * NT + lane;
       const int ic = min(i, npix - 1);
-      eoff_y[e] = ic / ww;
+      eoff_y[e] = (ic * a.ww_magic) >> 16;
       eoff_x[e] = ic - eoff_y[e] * ww;
       evalid[e] = i < npix;
       pidx[e] = i < NA ? i : -1;
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
 #pragma unroll
     for (int e = 0; e < FP; ++e) {
       const int jc = min(e * NT + lane, NF - 1);
-      foff_y[e] = jc / FW;
+      foff_y[e] = (jc * a.fw_magic) >> 16;
       foff_x[e] = jc - foff_y[e] * FW;
     }
   }
@@ -752,7 +759,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           const float diff = T1[e].x - s.x;  // computeImageDiff :110-116
           const float gx = T1[e].y + s.y;    // computeImageSum  :118-125
           const float gy = T1[e].z + s.z;
-          if (i >= 0) {
+          if (RUN > 0 || i >= 0) {
             prod[0 * NAs + i] = gx * gx;      // compute2X2GradientMatrix :127-146
             prod[1 * NAs + i] = gy * gy;
             prod[2 * NAs + i] = gx * gy;
@@ -810,7 +817,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
           const int i = pidx[e];
-          if (i >= 0) prod[i] = evalid[e] ? fabsf(T1[e].x - sI[e]) : 0.f;  // :193-208
+          if (RUN > 0 || i >= 0) prod[i] = evalid[e] ? fabsf(T1[e].x - sI[e]) : 0.f;  // :193-208
         }
         float tot[5];
         reduce(1, tot);
@@ -899,6 +906,7 @@ void fill_args(const gklt_params &P, const gklt_pyramid *py0, int n, bool epilog
   a.inv_ss = (P.subsampling & (P.subsampling - 1)) == 0 ? 1.0f / (float)P.subsampling : 0.f;
   a.ww = P.window_width;
   a.wh = P.window_height;
+  a.ww_magic = (65536 + a.ww - 1) / a.ww;
   a.step_factor = P.step_factor;
   a.min_det = P.min_determinant;
   a.min_disp = P.min_displacement;
@@ -984,6 +992,12 @@ WaveGeom wave_geom_compute(const gklt_ctx *ctx, int ww, int wh) {
   g.fpl = (g.NF + 63) / 64;
   g.lds = sizeof(float) * (size_t)(5 * prod_stride(g.NA) + 40) + (g.stage ? sizeof(float4) * (size_t)(g.fstride * (wh + 1 + 2 * g.halo) + 8) : 0);
   g.fits = g.epl <= 16 && g.fpl <= 16 && g.lds <= 48 * 1024;
+  // the lane mappings divide by the window and footprint widths with a 16-bit reciprocal
+  // (TrackArgs::ww_magic, fw_magic): exact for every index they see, or the window does not fit
+  for (int d : {ww, ww + 1 + 2 * g.halo}) {
+    const int magic = (65536 + d - 1) / d;
+    for (int j = 0; j < 64 * 16; ++j) g.fits = g.fits && ((j * magic) >> 16) == j / d;
+  }
   // footprint-in-registers sampling: the whole (w+1)(h+1) footprint in one wavefront
   // (track_impl 2 keeps the four gathers per element for A/B runs)
   g.frm = !g.stage && g.NF <= 64 && ctx->track_impl != 2;
@@ -1080,6 +1094,7 @@ int launch_track_streams(gklt_ctx *ctx, hipStream_t s, const Texel *const *tab, 
   fill_args(P, py0, M.nmax, false, mirror_stride, &a);
   a.halo = g.halo;
   a.fstride = g.fstride;
+  a.fw_magic = (65536 + P.window_width + 2 * g.halo) / (P.window_width + 1 + 2 * g.halo);
   TrackFrames F{};
   F.nframes = 1;
   F.mirror[0] = mirror;
@@ -1121,6 +1136,7 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
   const WaveGeom g = wave_geom(ctx, a.ww, a.wh);
   a.halo = g.halo;
   a.fstride = g.fstride;
+  a.fw_magic = (65536 + a.ww + 2 * g.halo) / (a.ww + 1 + 2 * g.halo);
   const dim3 block(64);
 
   if (ctx->track_impl != 1 && g.fits) {  // feature per wave
