@@ -14,7 +14,8 @@ LIB = os.path.join(HERE, "libgklt.so")
 SOURCES = ["gklt_host.cpp", "gklt_api.hip", "gklt_pyramid.hip", "gklt_pyramid_stream.hip", "gklt_track.hip", "gklt_pipeline.hip",
            "gklt_lookahead.hip", "gklt_multistream.hip", "gklt_bearing.hip", "gklt_select.hip",
            "gklt_ingest.hip", "gklt_ransac.hip"]
-HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h")]
+HEADERS = ["gklt_internal.h", os.path.join("..", "..", "include", "gklt.h"),
+           os.path.join("..", "..", "include", "gklt_order.h")]
 
 # -ffp-contract=off: the reference's arithmetic is unfused AVX (no FMA); fusing mul+add on the
 # GPU would change borderline status flags.  Correctly rounded fp32 divide/sqrt is hipcc's

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/gklt.h"
+#include "../../include/gklt_order.h"
 
 namespace gklt {
 

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_smooth(const SrcT *__restrict__ src, int
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 outputs, one per thread
     const int x = x0 / 2 + tx, y = y0 / 2 + ty;
     const float *p = sm + (2 * ty) * TW + 2 * tx;
-    const float v = (((p[0] + p[1]) + p[TW]) + p[TW + 1]) * 0.25f;
+    const float v = GKLT_MEAN2X2(p[0], p[1], p[TW], p[TW + 1]);
     if (x < w2 && y < h2) dst[(size_t)y * w2 + x] = v;
   }
 }
@@ -358,13 +358,13 @@ __global__ __launch_bounds__(NT) void k_smooth_fast(const SrcT *__restrict__ src
       if (x < w && y < h) dst[(size_t)y * w + x] = o[j];
     }
   } else {
-    // 2x2 mean (((p00 + p01) + p10) + p11) * 0.25: the odd neighbour comes from lane ^ 1
+    // 2x2 mean in the order of include/gklt_order.h: the odd neighbour comes from lane ^ 1
     const int x = x0 / 2 + (lane >> 1);
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const float a = o[2 * jj], c = o[2 * jj + 1];
       const float b = __shfl_xor(a, 1), d = __shfl_xor(c, 1);
-      const float m = (((a + b) + c) + d) * 0.25f;
+      const float m = GKLT_MEAN2X2(a, b, c, d);
       const int y = y0 / 2 + 2 * wave + jj;
       if (!(lane & 1) && x < w2 && y < h2) dst[(size_t)y * w2 + x] = m;
     }
@@ -698,7 +698,7 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
     for (int jj = 0; jj < RPW / 2; ++jj) {
       const float a = o[2 * jj], c = o[2 * jj + 1];
       const float b = __shfl_xor(a, 1), e = __shfl_xor(c, 1);
-      const float m = (((a + b) + c) + e) * 0.25f;
+      const float m = GKLT_MEAN2X2(a, b, c, e);
       const int y = y0 / 2 + RPW / 2 * wave + jj;
       if (!(lane & 1) && x < w2 && y < h2) down[(size_t)y * w2 + x] = m;
     }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64) void k_level_stream(StreamIO io, int stride, in
         if (yp & 1) {  // ya is even: rows (yp - 1, yp) form a block; its right column sits in lane + 1
           const v2f a = o_prev, c = o;
           const v2f b = v2f{quad_swap1(a.x), quad_swap1(a.y)}, e = v2f{quad_swap1(c.x), quad_swap1(c.y)};
-          const v2f m = (((a + b) + c) + e) * 0.25f;
+          const v2f m = GKLT_MEAN2X2(a, b, c, e);
           const int y2 = yp >> 1;
           if (yp >= ya && yp < yb && y2 < h2) {
             if (dnA) down[(size_t)y2 * w2 + (xa >> 1)] = m.x;

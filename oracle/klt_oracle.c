@@ -7,6 +7,7 @@
  * All file:line citations are relative to /root/reference/GSLAM/.
  */
 #include "klt_oracle.h"
+#include "../include/gklt_order.h"
 
 #include <limits.h>
 #include <math.h>
@@ -252,7 +253,7 @@ void ok_resize_linear(const float *src, int W, int H, float *dst, int W2, int H2
       const float *r0 = src + (size_t)(2 * y) * W, *r1 = r0 + W;
       int x;
       for (x = 0; x < W2; x++)
-        dst[(size_t)y * W2 + x] = (((r0[2 * x] + r0[2 * x + 1]) + r1[2 * x]) + r1[2 * x + 1]) * 0.25f;
+        dst[(size_t)y * W2 + x] = GKLT_MEAN2X2(r0[2 * x], r0[2 * x + 1], r1[2 * x], r1[2 * x + 1]);
     }
     return;
   }

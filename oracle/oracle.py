@@ -49,7 +49,7 @@ class Params(C.Structure):
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(os.path.join(_HERE, f)) for f in ("klt_oracle.c", "ransac_oracle.c")
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("klt_oracle.c", "ransac_oracle.c", "klt_oracle.h", os.path.join("..", "include", "gklt_order.h"))
     ):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libklt_oracle.so"], stdout=subprocess.DEVNULL)
 

@@ -82,3 +82,21 @@ def test_oracle_is_not_reachable_from_the_product():
                 if f.endswith((".py", ".h", ".hip", ".cpp")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "klt_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_summation_order_choices_are_defined_once():
+    """The 2x2 mean of the exact-half resize is an order CHOICE (OpenCV is not in the reference
+    tree): kernels and oracle take it from include/gklt_order.h, nobody spells it out locally, so a
+    fixture that settles the order changes one line for both sides."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    users = 0
+    for f in glob.glob(os.path.join(root, "gslam_amd", "csrc", "*")) + [os.path.join(root, "oracle", "klt_oracle.c")]:
+        text = open(f).read()
+        code = re.sub(r"//[^\n]*|/\*.*?\*/", "", text, flags=re.S)
+        assert "0.25f" not in code, "%s averages a 2x2 block without GKLT_MEAN2X2" % f
+        users += code.count("GKLT_MEAN2X2(")
+    assert users >= 5
+    hdr = open(os.path.join(root, "include", "gklt_order.h")).read()
+    assert "GKLT_MEAN2X2_PAIRWISE" in hdr and hdr.count("#define GKLT_MEAN2X2(") == 2
