@@ -236,6 +236,40 @@ def test_lookahead_11x11_capped_launch(klt, ok, gpu_ctx, waves):
             gpu_ctx.pinned_free(p)
 
 
+@pytest.mark.parametrize("ww,wh,waves", [(21, 21, 0), (21, 21, 29), (17, 19, 0)])
+def test_lookahead_large_window_row_run_launch(klt, ok, gpu_ctx, ww, wh, waves):
+    """The multi-frame launch of the as-shipped configuration (21x21, 2 levels; the row-run mapping
+    with the footprint staged in LDS, incl. the reuse of a staged footprint across passes and
+    frames), also with fewer wavefronts than features and with partial runs (17 wide)."""
+    H, W, n, B = 200, 320, 260, 5
+    f = _stream(H, W, B + 1, seed=23)
+    gp = klt.make_params(window=21, levels=2)
+    op = ok.make_params(window=21, levels=2)
+    for q in (gp, op):
+        q.window_width, q.window_height = ww, wh
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    val[5] = -3
+    ref = _oracle_lists(ok, op, f, x, y, val)
+    gpu_ctx.set_track_waves(waves)
+    la = klt.Lookahead(gpu_ctx, W, H, n, B)
+    outs = [gpu_ctx.pinned_array((3, n), np.float32) for _ in range(B)]
+    try:
+        la.upload_features(x, y, val)
+        la.start(f[0])
+        la.submit(f[1:B + 1], [o[1] for o in outs])
+        la.flush()
+        for k in range(B):
+            _same(outs[k][0], ref[k], "frame %d" % (k + 1))
+        assert (ref[-1][2] == 0).mean() > 0.7
+    finally:
+        gpu_ctx.set_track_waves(0)
+        la.close()
+        for _, p in outs:
+            gpu_ctx.pinned_free(p)
+
+
 def test_lookahead_full_size_c3(klt, ok, gpu_ctx):
     """BASELINE C3 as bench.py runs it: 4K frames, 16000 features, 5 levels, 11x11, batches through
     gklt_lookahead with the default cap of 4096 wavefronts (each follows ~4 features)."""
