@@ -183,6 +183,17 @@ extern "C" int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int
   return 0;
 }
 
+// n consecutive gklt_pipeline_step calls (what a C++ caller's frame loop does), for harnesses whose
+// foreign-function calls cost as much as a step's launches
+extern "C" int gklt_pipeline_run(gklt_pipeline *p, const uint8_t *const *frames, int n, int stride,
+                                 int on_device, void *const *host_out) {
+  if (!p || !frames || n < 0) return GKLT_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (int rc = gklt_pipeline_step(p, frames[i], stride, on_device, host_out ? host_out[i] : nullptr))
+      return rc;
+  return 0;
+}
+
 // gklt_pipeline_step with the next frame taken from an ingested gklt_frame (gklt_ingest.hip)
 extern "C" int gklt_pipeline_step_frame(gklt_pipeline *p, gklt_frame *next, void *host_out) {
   if (!p || !p->started || !next || frame_ctx(next) != p->ctx) return GKLT_EINVAL;

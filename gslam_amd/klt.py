@@ -386,6 +386,18 @@ class Pipeline:
         if keep is not None:
             self.sync()  # pageable host frame must stay alive until staged
 
+    def run(self, frames, host_outs=None):
+        """gklt_pipeline_run: one gklt_pipeline_step per frame, the loop itself in C.  frames:
+        (pointer, stride, on_device) tuples of device or page-locked host frames, same stride and
+        residency; host_outs: pointers (or None)."""
+        n = len(frames)
+        if n == 0:
+            return
+        stride, dev = frames[0][1], frames[0][2] if len(frames[0]) > 2 else 1
+        fp = (C.c_void_p * n)(*[f[0] for f in frames])
+        ho = (C.c_void_p * n)(*host_outs) if host_outs is not None else None
+        _check(lib().gklt_pipeline_run(self.h, fp, n, int(stride), int(dev), ho))
+
     def upload_features(self, x, y, val):
         self._seed = (np.ascontiguousarray(x, np.float32), np.ascontiguousarray(y, np.float32),
                       np.ascontiguousarray(val, np.int32))

@@ -258,6 +258,12 @@ int gklt_pipeline_start(gklt_pipeline *p, const uint8_t *img0, const uint8_t *im
  * frame (img_on_device = 0) must stay valid until the step's staging copy has run. */
 int gklt_pipeline_step(gklt_pipeline *p, const uint8_t *img_next, int stride, int img_on_device,
                        void *host_out);
+/* n consecutive gklt_pipeline_step() calls, frames[i] / host_out[i] being the arguments of call i
+ * (host_out may be NULL): exactly the loop a C++ caller runs (System.cpp:501-518), for harnesses
+ * whose foreign-function calls cost as much as a step's launches.  No counterpart in the
+ * reference. */
+int gklt_pipeline_run(gklt_pipeline *p, const uint8_t *const *frames, int n, int stride,
+                      int img_on_device, void *const *host_out);
 /* Replaces the tracked list (keyframe re-seeding, System.cpp:415-420); ordered with the steps.
  * x / y / val may be pageable and may be reused as soon as the call returns (they are copied
  * into a page-locked mirror of the list first); the same holds for gklt_flist_upload,

@@ -391,6 +391,50 @@ def test_pipeline_matches_oracle(klt, ok, gpu_ctx, pinned_out):
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("device_frames", [True, False])
+def test_pipeline_run_is_a_loop_of_steps(klt, ok, gpu_ctx, device_frames):
+    """gklt_pipeline_run(frames[0..n)) = n gklt_pipeline_step calls issued from C: the list after
+    every frame (one pinned host buffer per frame) equals the oracle's, for device-resident and for
+    page-locked host frames."""
+    H, W, nfr, n = 180, 320, 10, 300
+    f = _stream(H, W, nfr, seed=31)
+    gp = klt.make_params(window=7, levels=3)
+    op = ok.make_params(window=7, levels=3)
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+    val = np.zeros(n, np.int32)
+    if device_frames:
+        ptrs = [gpu_ctx.device_upload(a) for a in f]
+    else:
+        host = [gpu_ctx.pinned_array((H, W), np.uint8) for _ in f]
+        for (a, _), src in zip(host, f):
+            a[:] = src
+        ptrs = [p for _, p in host]
+    outs = [gpu_ctx.pinned_array((3, n), np.float32) for _ in range(nfr - 2)]
+    pipe = klt.Pipeline(gpu_ctx, W, H, n)
+    try:
+        pipe.upload_features(x, y, val)
+        dev = 1 if device_frames else 0
+        pipe.start((ptrs[0], W, dev), (ptrs[1], W, dev))
+        # steps t = 1 .. nfr-2: step t preloads frame t+1 and tracks t-1 -> t
+        pipe.run([(ptrs[t + 1], W, dev) for t in range(1, nfr - 1)], [o[1] for o in outs])
+        pipe.sync()
+        rx, ry, rv = x, y, val
+        prev = ok.compute_pyramid(op, f[0])
+        for t in range(1, nfr - 1):
+            cur = ok.compute_pyramid(op, f[t])
+            rx, ry, rv = ok.track_features(op, prev, cur, rx, ry, rv)[:3]
+            o = outs[t - 1][0]
+            _assert_same((o[0], o[1], o[2].view(np.int32)), (rx, ry, rv))
+            prev = cur
+    finally:
+        pipe.close()
+        for _, p in outs:
+            gpu_ctx.pinned_free(p)
+        for p in ptrs:
+            (gpu_ctx.device_free if device_frames else gpu_ctx.pinned_free)(p)
+
+
 def test_build_and_track_from_two_host_threads(klt, ok, gpu_ctx):
     """System.cpp:508-518: computePyramid(t+1) runs on a std::thread while KLTTrackFeatures works on
     the other two ring buffers.  Same pattern through the C ABI (ctypes releases the GIL): one
