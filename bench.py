@@ -183,20 +183,8 @@ class Stream:
         self.t = t + 1
 
     def run(self, nframes):
-        """nframes steps; the per-frame gklt_pipeline_step calls are issued from C
-        (gklt_pipeline_run) in chunks that end where a re-seed is due -- the cost of a C++ caller's
-        loop (tools/pipe_host.cpp), not of a Python call per frame."""
-        done = 0
-        while done < nframes:
-            t = self.t
-            if t >= self.next_reseed:
-                self.pipe.upload_features(*self.seeds)
-                self.next_reseed += RESEED_EVERY
-            k = min(nframes - done, self.next_reseed - t, 32)
-            self.pipe.run([self.frame(u + 1) for u in range(t, t + k)],
-                          [self.host[u % 4][1] for u in range(t, t + k)])
-            self.t = t + k
-            done += k
+        for _ in range(nframes):
+            self.step()
 
     def sync(self):
         self.pipe.sync()
@@ -894,7 +882,7 @@ def main(argv=None):
                              "gklt_pipeline_step: eager, 2 alternating streams, 1 event wait/frame",
                    "parallelism": "stream-sharded x%d, no collective" % world},
         "frame_at_a_time": {"value": tracked1 / dt1, "ms_per_step": dt1 / k1 * 1e3, "steps": k1,
-                            "mode": "one gklt_pipeline_step per frame (preload depth 1, as System.cpp:501-518), the calls issued from C (gklt_pipeline_run, chunks of <= 32 frames: a C++ caller's loop without a Python call per frame), rank 0"},
+                            "mode": "gklt_pipeline_step (preload depth 1, as System.cpp:501-518), rank 0"},
         "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                        "step_complete_p50": float(np.percentile(lat_full, 50)),
                        "step_complete_p99": float(np.percentile(lat_full, 99)),
