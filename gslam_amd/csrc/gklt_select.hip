@@ -18,6 +18,7 @@
 //      k_rank_assign ranks the accepted set and writes slot[rank].
 #include <algorithm>
 #include <cstdlib>
+#include <functional>
 #include <utility>
 #include <vector>
 
@@ -896,6 +897,9 @@ struct UniScratch;
 void uni_free(UniScratch *u);
 constexpr int kMaxRounds = 4096;
 constexpr int kRoundBatch = 24;  // rounds per host sync: a converged round costs ~3 us, a sync ~25 us
+// words of h_counters behind the per-round counters: values fetched by the same poll as the
+// counters (every host synchronisation leaves the GPU idle for ~25-40 us)
+constexpr int kPollExtra = 4, kPollNeed64 = kMaxRounds + 1, kPollCount = kMaxRounds + 2;
 
 void sel_free(SelScratch *s) {
   if (!s) return;
@@ -940,7 +944,7 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
     GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
     GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
     GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
-    GKLT_HIP(hipHostMalloc(&s->h_counters, sizeof(unsigned) * (kMaxRounds + 1), hipHostMallocDefault));
+    GKLT_HIP(hipHostMalloc(&s->h_counters, sizeof(unsigned) * (kMaxRounds + 1 + kPollExtra), hipHostMallocDefault));
   }
   if (s->w != w || s->h != h) s->last_rounds[0] = s->last_rounds[1] = 0;  // round hint of another image size
   s->w = w;
@@ -1245,6 +1249,8 @@ __global__ void k_u_fill(int from, int to, float *__restrict__ fx, float *__rest
 
 struct UniScratch {
   int ncell = 0, w = 0, h = 0;
+  int rank_cw = 0, rank_ch = 0;  // grid the visiting ranks on the device were computed for
+  int *h_cellcount = nullptr;    // pinned copy of cellcount (read in one poll with the tail flags)
   unsigned *state0 = nullptr, *pos = nullptr, *rank = nullptr, *flags = nullptr;
   unsigned long long *cellmax = nullptr, *tinfo = nullptr;
   int *cellcount = nullptr;
@@ -1256,6 +1262,7 @@ void uni_free(UniScratch *u) {
   (void)hipFree(u->state0); (void)hipFree(u->pos); (void)hipFree(u->rank); (void)hipFree(u->flags);
   (void)hipFree(u->cellmax); (void)hipFree(u->tinfo); (void)hipFree(u->cellcount);
   (void)hipFree(u->cellrank);
+  if (u->h_cellcount) (void)hipHostFree(u->h_cellcount);
   delete u;
 }
 
@@ -1279,14 +1286,21 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
     GKLT_HIP(hipMalloc(&u->tinfo, 4 * sizeof(unsigned long long)));
     GKLT_HIP(hipMalloc(&u->cellcount, sizeof(int) * ncell));
     GKLT_HIP(hipMalloc(&u->cellrank, sizeof(unsigned short) * ncell));
+    GKLT_HIP(hipHostMalloc(&u->h_cellcount, sizeof(int) * ncell, hipHostMallocDefault));
   }
   *out = u;
   return 0;
 }
 
 // runs fixpoint rounds until no candidate is undecided
+// `tail` (optional) is enqueued behind every batch of rounds, before the poll: work that only
+// makes sense on the converged state but is cheap enough to run speculatively (the collection of
+// the accepted candidates), so that its result comes back with the poll that finds the rounds
+// converged instead of costing a host synchronisation of its own.  The poll also fetches the
+// need64 flag (h_counters[kPollNeed64]) and counters[0] (h_counters[kPollCount]).
 static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
-                      UCaps caps, int r, int *round_io, bool keys32 = false) {
+                      UCaps caps, int r, int *round_io, bool keys32 = false,
+                      const std::function<int()> &tail = {}) {
   const int w = sc->w, h = sc->h;
   const size_t lds = keys32 ? mis32_lds_bytes(r) : mis_lds_bytes(r);
   if (lds > 160 * 1024) {
@@ -1332,8 +1346,14 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
       }
     }
     GKLT_HIP(hipGetLastError());
+    if (tail)
+      if (int rc = tail()) return rc;
     GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
                             sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollNeed64, u->flags + 2, sizeof(unsigned),
+                            hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollCount, sc->counters, sizeof(unsigned),
+                            hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
     for (int k = first; k < round && !done; ++k)
       if (sc->h_counters[k] == 0) {
@@ -1374,7 +1394,8 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
 
   // initializeGridSequence (:1033-1061): cells by squared distance from the grid centre
   // (ties, unspecified in the reference's std::sort, by index)
-  {
+  // (kept on the device from one selection to the next: the order depends on the grid only)
+  if (u->rank_cw != cw || u->rank_ch != ch) {
     std::vector<std::pair<float, int>> seq(ncell);
     for (int i = 0; i < ncell; ++i) {
       const float dY = (float)(i / cw - (float)ch / 2.0);
@@ -1387,6 +1408,8 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     GKLT_HIP(hipMemcpyAsync(u->cellrank, rank.data(), sizeof(unsigned short) * ncell,
                             hipMemcpyHostToDevice, s));
     GKLT_HIP(hipStreamSynchronize(s));
+    u->rank_cw = cw;
+    u->rank_ch = ch;
   }
   const UGrid g{gridW, gridH, cw, ch, u->cellrank};
   const dim3 pgrid((w + 255) / 256, h);
@@ -1411,42 +1434,41 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   // several microseconds per cell: 12 ms, against 0.64 ms for these rounds.)
   const int tcx = (MW + 2 * r - 2) / gridW + 2, tcy = (MH + 2 * r - 2) / gridH + 2;
   const bool keys32 = ctx->sel_impl != 1 && tcx * tcy <= kU32Cells;
-  if (keys32) GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
-  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys32)) return rc;
-  if (keys32) {
-    unsigned need64 = 0;
-    GKLT_HIP(hipMemcpyAsync(&need64, u->flags + 2, sizeof need64, hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipStreamSynchronize(s));
-    if (need64) {
-      GKLT_HIP(hipMemcpyAsync(sc->state, u->state0, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
-      GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
-      round = 1;
-      if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, false)) return rc;
-    }
-  }
-
-  auto collect_and_rank = [&](unsigned *n_acc) -> int {
+  // The accepted candidates are collected behind every batch of rounds, so that their number
+  // arrives with the poll that sees the rounds converged (one host synchronisation instead of
+  // three: rounds, need64, count); the ranking needs the count for its grid and follows the poll.
+  auto enqueue_collect = [&]() -> int {
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(k_u_collect, collect_grid(w, h), dim3(256), 0, s, sc->state, w, h, g,
                        sc->list, u->pos, sc->counters, (unsigned)sc->cap_list);
-    GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipStreamSynchronize(s));
-    *n_acc = sc->h_counters[0];
-    if (*n_acc > (unsigned)sc->cap_list) {
+    GKLT_HIP(hipGetLastError());
+    return 0;
+  };
+  auto enqueue_rank = [&](unsigned n_acc) -> int {
+    if (n_acc > (unsigned)sc->cap_list) {
       set_error("accepted-feature list overflow");
       return GKLT_ECAPACITY;
     }
-    if (*n_acc) {
-      GKLT_HIP(hipMemsetAsync(u->rank, 0, sizeof(unsigned) * *n_acc, s));
-      hipLaunchKernelGGL(k_rank_partial, dim3((*n_acc + 255) / 256, kRankSlices), dim3(256), 0, s,
-                         sc->list, sc->counters, *n_acc, u->rank);
+    if (n_acc) {
+      GKLT_HIP(hipMemsetAsync(u->rank, 0, sizeof(unsigned) * n_acc, s));
+      hipLaunchKernelGGL(k_rank_partial, dim3((n_acc + 255) / 256, kRankSlices), dim3(256), 0, s,
+                         sc->list, sc->counters, n_acc, u->rank);
     }
     GKLT_HIP(hipGetLastError());
     return 0;
   };
+  GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
+  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys32, enqueue_collect)) return rc;
+  if (keys32 && sc->h_counters[kPollNeed64]) {
+    GKLT_HIP(hipMemcpyAsync(sc->state, u->state0, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
+    GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
+    GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
+    round = 1;
+    if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, false, enqueue_collect)) return rc;
+  }
 
-  unsigned nacc = 0;
-  if (int rc = collect_and_rank(&nacc)) return rc;
+  unsigned nacc = sc->h_counters[kPollCount];
+  if (int rc = enqueue_rank(nacc)) return rc;
   int free_slot = 0;
   if ((int)nacc >= n0 && n0 > 0) {
     // the slots ran out at T, the candidate that took the last original slot
@@ -1465,12 +1487,12 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
                u->cellcount};
     hipLaunchKernelGGL(k_u_reset, pgrid, dim3(256), 0, s, sc->state, u->state0, w, h, g, u->tinfo);
     GKLT_HIP(hipMemsetAsync(u->cellcount, 0, sizeof(int) * ncell, s));
-    GKLT_HIP(hipMemcpyAsync(u->cellcount + cellT, &a1, sizeof(int), hipMemcpyHostToDevice, s));
+    GKLT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(u->cellcount + cellT), a1, 1, s));
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
-    GKLT_HIP(hipStreamSynchronize(s));  // a1 is a stack variable
     round = 1;
-    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round)) return rc;  // phase B
-    if (int rc = collect_and_rank(&nacc)) return rc;
+    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round, false, enqueue_collect)) return rc;  // phase B
+    nacc = sc->h_counters[kPollCount];
+    if (int rc = enqueue_rank(nacc)) return rc;
     // is a grown slot left unfilled?  (see the comment at the top of this section)
     unsigned long long hA[4] = {0, 0, 0, 0};
     unsigned hflags[2] = {0, 0};
@@ -1482,11 +1504,12 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
                        u->flags);
     GKLT_HIP(hipMemcpyAsync(hA, u->tinfo, sizeof hA, hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipMemcpyAsync(hflags, u->flags, sizeof hflags, hipMemcpyDeviceToHost, s));
+    // every cell's count comes along (8 KB): which one is needed is known only from hA
+    GKLT_HIP(hipMemcpyAsync(u->h_cellcount, u->cellcount, sizeof(int) * ncell, hipMemcpyDeviceToHost, s));
     GKLT_HIP(hipStreamSynchronize(s));
     const int ax = (int)(hA[1] % (unsigned)w), ay = (int)(hA[1] / (unsigned)w);
     const int cellA = std::min(ay / gridH, ch - 1) * cw + std::min(ax / gridW, cw - 1);
-    GKLT_HIP(hipMemcpyAsync(&cntA, u->cellcount + cellA, sizeof(int), hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipStreamSynchronize(s));
+    cntA = u->h_cellcount[cellA];
     free_slot = (hflags[1] || (hflags[0] && cntA <= minFeat)) ? 1 : 0;
   }
   const int total = std::max(n0, (int)nacc + free_slot);  // :1257 grows, :1296-1312 pads
