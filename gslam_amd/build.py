@@ -26,6 +26,10 @@ FLAGS = [
 ]
 
 
+FMA_SRC = os.path.join(CSRC, "gklt_pyramid.hip")
+FMA_OBJ = os.path.join(OBJ, "gklt_pyramid_fma.hip.o")
+
+
 def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
@@ -58,6 +62,12 @@ def build(force=False, verbose=False, extra=()):
     for src in sources():
         if force or extra or _newer(_obj(src), [src] + _deps()):
             jobs.append([hipcc] + FLAGS + list(extra) + ["-x", "hip", "-c", src, "-o", _obj(src)])
+    # the fused level kernels a second time with mul+add contraction: pyramid impl 4 (tolerance
+    # variant, never the default; see gklt_pyramid.hip)
+    if force or extra or _newer(FMA_OBJ, [FMA_SRC] + _deps()):
+        flags = [f for f in FLAGS if f != "-ffp-contract=off"] + ["-ffp-contract=fast", "-DGKLT_PYR_FMA", "-Wno-unused-function",
+                                                                        "-Wno-unneeded-internal-declaration"]
+        jobs.append([hipcc] + flags + list(extra) + ["-x", "hip", "-c", FMA_SRC, "-o", FMA_OBJ])
 
     def run(cmd):
         if verbose:
@@ -66,7 +76,7 @@ def build(force=False, verbose=False, extra=()):
 
     with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in sources()] + ["-o", LIB])
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in sources()] + [FMA_OBJ, "-o", LIB])
     return LIB
 
 

@@ -854,9 +854,11 @@ extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
   return 0;
 }
 
-// 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels
+// 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels; 3 = the
+// streaming form of the fused kernel; 4 = the fused kernel with mul+add contracted into FMAs (NOT
+// bit-identical: inside north_star's 1e-4 relative tolerance; never the default)
 extern "C" int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl) {
-  if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
+  if (!ctx || impl < 0 || impl > 4) return GKLT_EINVAL;
   ctx->pyr_impl = impl;
   return 0;
 }

@@ -75,7 +75,7 @@ struct gklt_ctx {
   int d_rot_capacity = 0;   // in doubles
   void *noalloc_scratch = nullptr;  // this GPU's address of gklt_api.hip's `scratch` array
   // profiling
-  int pyr_impl = 0;    // gklt_ctx_set_pyramid_impl: 0 default, 1 separate kernels, 2 tile kernels, 3 streaming kernels
+  int pyr_impl = 0;    // gklt_ctx_set_pyramid_impl: 0 default, 1 separate kernels, 2 tile kernels, 3 streaming kernels, 4 contracted (FMA) tile kernels
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
   int sel_impl = 0;         // plain selector rounds: 0 = 32-bit keys, 1 = 64-bit keys
   int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch
@@ -146,6 +146,10 @@ int launch_gradients_planar(gklt_ctx *ctx, hipStream_t s, const float *src, int 
 // fused level kernels (one launch per level): see gklt_pyramid.hip
 bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d);
 int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
+                 int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
+                 const Taps &d, float *img0_out);
+// the same kernels built with mul+add contraction (gklt_pyramid.hip compiled -DGKLT_PYR_FMA)
+int launch_level_fma(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out);
 // streaming form of the fused level kernel (gklt_pyramid_stream.hip)

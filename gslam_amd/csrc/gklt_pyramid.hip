@@ -862,12 +862,21 @@ int launch_level_inst(gklt_ctx *ctx, hipStream_t s, int prof_id, const LevelIO &
 
 // Radii the fused level kernel is instantiated for: grad_sigma = 1.0 (R 3), pyramid sigma 1.8
 // (subsampling 2 * 0.9, R 5), level-0 smoothing radius 1..6 (windows up to 29 px; the as-shipped 21x21 has radius 6).
+#ifndef GKLT_PYR_FMA
 bool level_fusable(const Taps *s0, const Taps *pyr, const Taps &g, const Taps &d) {
   if (g.r != 3 || d.r != 3) return false;
   if (pyr && pyr->r != 5) return false;
   if (s0 && (s0->r < 1 || s0->r > 6)) return false;
   return true;
 }
+#else
+// This translation unit is compiled a second time with -DGKLT_PYR_FMA -ffp-contract=fast
+// (gslam_amd/build.py): the same fused level kernels with mul+add contracted into FMAs, exported as
+// launch_level_fma and selected by gklt_ctx_set_pyramid_impl(ctx, 4).  Results are NOT the
+// oracle's bits any more; they stay inside north_star's tolerance (1e-4 relative on every plane:
+// tests/test_gpu_pyramid.py::test_contracted_level_kernels_within_tolerance).  Never the default.
+#define launch_level launch_level_fma
+#endif
 
 // Level `level` of `n` pyramids in one launch (n <= GKLT_MAX_LOOKAHEAD).  Level 0 reads the u8
 // frames src[i] (smoothing s0); level l > 0 reads py[i]->lv[l].img.  pyr == nullptr: no
@@ -881,8 +890,12 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
   // faster than the tile kernel on batched level-0 launches (131 vs 161 us per 16 C2 frames), but
   // next to the tracker launch a batch overlaps with it does not shorten the batch,
   // so the tile kernel stays the default.
+#ifndef GKLT_PYR_FMA
   if (!img0_out && ctx->pyr_impl == 3 && level_streamable(py[0]->lv[level].w, py[0]->lv[level].h, level, s0))
     return launch_level_stream(ctx, s, py, src, n, stride, level, s0, pyr, g, d);
+  if (ctx->pyr_impl == 4)  // contracted arithmetic (tolerance variant, see the #else branch above)
+    return launch_level_fma(ctx, s, py, src, n, stride, level, s0, pyr, g, d, img0_out);
+#endif
   LevelIO io{};
   const Level &L = py[0]->lv[level];
   int w2 = 0, h2 = 0;
@@ -920,6 +933,7 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
   return GKLT_EINVAL;
 }
 
+#ifndef GKLT_PYR_FMA
 int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,
                      const Taps &g, float *dst) {
   return launch_smooth_any<uint8_t, 0>(ctx, s, GKLT_K_SMOOTH0, src, stride, w, h, g, dst, 0, 0);
@@ -987,5 +1001,7 @@ int launch_tex_insert(gklt_ctx *ctx, hipStream_t s, Texel *tex, int n, int comp,
   GKLT_HIP(hipGetLastError());
   return 0;
 }
+
+#endif  // !GKLT_PYR_FMA
 
 }  // namespace gklt

@@ -444,7 +444,10 @@ int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
  * (default); 1 = always the separate smooth / decimate / gradient kernels; 2 = as 0; 3 = fused
  * launches take the streaming kernel (one wavefront per 112-column strip marching down the rows,
  * column windows in registers) where it applies (frames of at least 192 x 192, level-0 windows
- * 7x7 / 11x11 / 21x21).  Identical results. */
+ * 7x7 / 11x11 / 21x21).  Identical results for 0..3.  4 = the fused kernels of 0 with every
+ * mul+add contracted into an FMA: NOT the reference's unfused AVX arithmetic any more -- planes
+ * agree with it to 1e-4 relative (the tolerance this path is specified to), positions and status
+ * flags of a few features per thousand differ in the last digits.  Never the default. */
 int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
 /* Plain / ...2 selector rounds: 0 = 32-bit keys in LDS (default), 1 = the 64-bit-key rounds the
  * Uniform selector uses.  Identical results. */

@@ -197,3 +197,61 @@ def test_fused_level_kernels_tile_and_streaming(klt, ok, H, W, win, L, impl):
         assert (a.view(np.uint32) == b.view(np.uint32)).all(), (impl, i)
     py.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("H,W,window,levels", [(270, 480, 7, 4), (200, 333, 21, 2), (1080, 1920, 7, 4)])
+def test_contracted_level_kernels_within_tolerance(klt, ok, gpu_ctx, H, W, window, levels):
+    """Pyramid impl 4 (the fused level kernels with mul+add contracted into FMAs) is NOT
+    bit-identical to the oracle; it must stay inside north_star's tolerance: every plane within 1e-4
+    of the plane's magnitude (measured: a few 1e-7), and it must really differ from the exact kernels
+    somewhere (otherwise the variant is not being run)."""
+    img = _frame(H, W)
+    gp = klt.make_params(window=window, levels=levels)
+    op = ok.make_params(window=window, levels=levels)
+    gpu_ctx.set_params(gp)
+    gpu_ctx.set_pyramid_impl(4)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    try:
+        pyr.build(img)
+        got = pyr.planes()
+    finally:
+        pyr.close()
+        gpu_ctx.set_pyramid_impl(0)
+    ref = ok.compute_pyramid(op, img)
+    differs = False
+    for i, (a, b) in enumerate(zip(got, ref)):
+        scale = max(float(np.abs(b).max()), 1.0)
+        err = float(np.abs(a - b).max())
+        assert err <= 1e-4 * scale, "level %d plane %d: max abs error %g against magnitude %g" % (i // 3, i % 3, err, scale)
+        differs |= bool((a.view(np.uint32) != b.view(np.uint32)).any())
+    assert differs
+
+
+def test_contracted_level_kernels_end_to_end_c2(klt, ok, gpu_ctx):
+    """north_star's end-to-end bar for the tolerance variant at C2 full size: tracking on impl-4
+    pyramids against the oracle on its own pyramids -- positions within 0.01 px and identical status
+    for at least 99.9 % of the features."""
+    cfg = synth.CONFIGS["C2"]
+    H, W, n = cfg["H"], cfg["W"], cfg["n"]
+    T = synth.base_texture(H, W)
+    f0, f1 = synth.render_frame(T, H, W, 0), synth.render_frame(T, H, W, 1)
+    gp = klt.make_params(window=cfg["window"], levels=cfg["levels"])
+    op = ok.make_params(window=cfg["window"], levels=cfg["levels"])
+    gpu_ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, gp.borderx, nx=cfg["lattice"][0], ny=cfg["lattice"][1])
+    val = np.zeros(len(x), np.int32)
+    gpu_ctx.set_pyramid_impl(4)
+    p0, p1 = klt.Pyramid(gpu_ctx, W, H), klt.Pyramid(gpu_ctx, W, H)
+    try:
+        p0.build(f0); p1.build(f1)
+        gx, gy, gv = klt.KLTTrackFeatures(gpu_ctx, p0, p1, x, y, val)[:3]
+    finally:
+        p0.close(); p1.close()
+        gpu_ctx.set_pyramid_impl(0)
+    ok.set_threads(8)
+    rx, ry, rv = ok.track_features(op, ok.compute_pyramid(op, f0), ok.compute_pyramid(op, f1), x, y, val)[:3]
+    same_status = gv == rv
+    assert same_status.mean() >= 0.999, "status agreement %.5f" % same_status.mean()
+    both = same_status & (rv == 0)
+    d = np.maximum(np.abs(gx[both] - rx[both]), np.abs(gy[both] - ry[both]))
+    assert (d <= 0.01).mean() >= 0.999, "positions: %.5f within 0.01 px, max %g" % ((d <= 0.01).mean(), d.max())
