@@ -1,6 +1,3 @@
-// stand-in for convolve.h:12-13
+// forwards to the one stand-in header of this directory
 #pragma once
-#include <thread>
-#include "KLT.h"
-void computeGradients(const cv::Mat &img, cv::Mat &gradx, cv::Mat &grady, float sigma, std::thread *threads = NULL);
-void computeSmoothedImage(const cv::Mat &img, cv::Mat &dst, float sigma);
+#include "gslam_mock_api.h"

@@ -1,6 +1,3 @@
-// stand-in for error.h (KLTError prints and exits, KLTWarning prints; error.cpp:21-53)
+// forwards to the one stand-in header of this directory
 #pragma once
-#include <stdarg.h>
-#include <stdio.h>
-void KLTError(char *fmt, ...);
-void KLTWarning(char *fmt, ...);
+#include "gslam_mock_api.h"

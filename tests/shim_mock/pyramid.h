@@ -1,5 +1,4 @@
-// stand-in for pyramid.h:11
+// forwards to the one stand-in header of this directory
 #pragma once
-#include "convolve.h"
+#include "gslam_mock_api.h"
 #include "opencv2/imgproc/imgproc.hpp"
-void computePyramid(KLT_TrackingContext tc, const cv::Mat &img, std::vector<cv::Mat> &pyramid);
