@@ -1036,6 +1036,8 @@ void dispatch_w(const WaveGeom &g, int nwaves, hipStream_t s, const TrackArgs &a
     else if (epl <= 4) GKLT_TRACK_W(4, 0, 0);
     else if (epl <= 8) GKLT_TRACK_W(8, 0, 0);
     else GKLT_TRACK_W(16, 0, 0);
+  } else if (epl <= 2 && fpl <= 3 && nec == 16) {
+    GKLT_TRACK_W(2, 3, 16);  // 11x11 staged (track_impl 3)
   } else if (epl <= 7 && fpl <= 9 && nec == 56) {
     GKLT_TRACK_W(7, 9, 56);  // 21x21
   } else if (epl <= 1) {
