@@ -587,6 +587,44 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     o.z = g.y;
     return o;
   };
+  // RUN: all EPL elements of the lane's run, the upper texel row first and the lower one after it
+  // (RUN + 1 texels in registers at a time instead of 2 RUN + 2); the same expression per element,
+  // (t00 w0 + t01 w1) + (t10 w2 + t11 w3)
+  auto fp_sample_run = [&](const Bilin &b, int ox, int oy, float3 (&out)[EPL]) {
+    const float4 *q = fp + (eoff_y[0] + oy) * FS + (eoff_x[0] + ox);
+    f32x2 ga[EPL];
+    float ia[EPL];
+    {
+      float4 t[EPL + 1];
+#pragma unroll
+      for (int e = 0; e <= EPL; ++e) t[e] = q[e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        ga[e] = f32x2{t[e].x, t[e].y} * b.w0 + f32x2{t[e + 1].x, t[e + 1].y} * b.w1;
+        ia[e] = t[e].z * b.w0 + t[e + 1].z * b.w1;
+      }
+    }
+    {
+      float4 t[EPL + 1];
+#pragma unroll
+      for (int e = 0; e <= EPL; ++e) t[e] = q[FS + e];
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        const f32x2 g = ga[e] + (f32x2{t[e].x, t[e].y} * b.w2 + f32x2{t[e + 1].x, t[e + 1].y} * b.w3);
+        out[e].x = ia[e] + (t[e].z * b.w2 + t[e + 1].z * b.w3);
+        out[e].y = g.x;
+        out[e].z = g.y;
+      }
+    }
+  };
+  auto sample_all = [&](const Bilin &b, int ox, int oy, float3 (&out)[EPL]) {
+    if constexpr (RUN > 0) {
+      fp_sample_run(b, ox, oy, out);
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) out[e] = fp_sample(e, b, ox, oy);
+    }
+  };
   // ordered reduction of nq quantities whose per-element products sit in prod[q][0..NA)
   auto reduce = [&](int nq, float (&tot)[5]) {
     __syncthreads();
@@ -595,11 +633,17 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       const int q = lane >> 3, k = lane & 7;
       const float *p = prod + q * NAs + k;
       if constexpr (NEC > 0 && NEC <= 64) {
-        float t[NEC];
+        // reads in flight in blocks of at most 28 (register pressure), adds in element order
+        constexpr int HB = NEC > 32 ? (NEC + 1) / 2 : NEC;
 #pragma unroll
-        for (int u = 0; u < NEC; ++u) t[u] = p[u * SL];
+        for (int h0 = 0; h0 < NEC; h0 += HB) {
+          float t[HB];
 #pragma unroll
-        for (int u = 0; u < NEC; ++u) acc = acc + t[u];
+          for (int u = 0; u < HB; ++u) t[u] = p[min(h0 + u, NEC - 1) * SL];
+#pragma unroll
+          for (int u = 0; u < HB; ++u)
+            if (h0 + u < NEC) acc = acc + t[u];
+        }
       } else {
         // groups of 8 independent LDS reads (clamped index), then the adds in element order
         for (int j0 = 0; j0 < nec; j0 += 8) {
@@ -733,13 +777,11 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         __syncthreads();      // previous readers of fp are done
         fp_store(f1);
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) T1[e] = fp_sample(e, b1, HL, HL);
+        sample_all(b1, HL, HL, T1);
         __syncthreads();
         fp_store(f2);
         __syncthreads();
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2, HL, HL);
+        sample_all(b2, HL, HL, S2);
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) T1[e] = gather3(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
@@ -788,8 +830,7 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         if (STAGE) {
           int ox, oy;
           stage2(b2.xt - hw, b2.yt - hh, ox, oy);
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) S2[e] = fp_sample(e, b2, ox, oy);
+          sample_all(b2, ox, oy, S2);
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) S2[e] = gather3(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
