@@ -77,8 +77,9 @@ struct gklt_ctx {
   // profiling
   int pyr_impl = 0;    // gklt_ctx_set_pyramid_impl: 0 default, 1 separate kernels, 2 tile kernels, 3 streaming kernels, 4 contracted (FMA) tile kernels
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
-  int sel_impl = 0;         // plain selector rounds: 0 = 32-bit keys, 1 = 64-bit keys
-  int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch
+  int sel_impl = 0;         // suppression rounds: 0 = box tops (dense 32-bit keys where the radius rules them out), 1 = dense 64-bit keys, 2 = dense 32-bit keys
+  int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch (dense rounds)
+  int sel_tops_iters = 12;  // the same for the rounds on box tops, whose iterations cost less
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;
   struct Span {

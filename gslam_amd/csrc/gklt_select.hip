@@ -286,6 +286,14 @@ __device__ __forceinline__ void window_group(const unsigned long long *k, const 
 // `gate`: the tile is skipped when neither it nor one of its 8 neighbours decided anything in the
 // previous launch (prev_changed) -- it has already drawn every conclusion from that halo.
 constexpr int kStays = 1, kRejected = 0, kAcceptedNow = 2;
+// Staging loads: the addresses are clamped so that the loads can be unconditional and in flight
+// together, but left alone the compiler sinks every load into the in-image test that uses its
+// value and waits for it there -- one memory round trip per entry (seen in the ISA, round 3: 12
+// serial round trips per tile and launch).  Naming the whole batch as operands of one empty asm
+// statement makes all of them complete before the first use.
+#define GKLT_ISSUE_TOGETHER_12(v)                                                                  \
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]),        \
+                    "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]))
 // R >= 0: the radius as a compile-time constant (window loops unroll, their LDS reads are issued
 // together, staging divides by a constant); R < 0: radius r_rt.
 template <int R, typename KeyF, typename DecideF>
@@ -351,14 +359,15 @@ __device__ __forceinline__ void mis_round_tile(const unsigned *__restrict__ stat
       tyv[u] = i / inW;
       txv[u] = i - tyv[u] * inW;
       const int x = x0 - r + txv[u], y = y0 - r + tyv[u];
-      const unsigned v = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
-      sv[u] = (x >= 0 && x < w && y >= 0 && y < h) ? v : 0u;
+      sv[u] = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
     }
+    GKLT_ISSUE_TOGETHER_12(sv);
 #pragma unroll
     for (int u = 0; u < kStage; ++u) {
       if (i0 + u * MT < total) {
         const int tx = txv[u], ty = tyv[u];
-        const unsigned s = sv[u];
+        const int x = x0 - r + tx, y = y0 - r + ty;
+        const unsigned s = (x >= 0 && x < w && y >= 0 && y < h) ? sv[u] : 0u;
         const bool a = (s & kAccepted) != 0;
         key[ty * S + tx] = (s != 0 && !a) ? keyf(s, x0 - r + tx, y0 - r + ty) : 0ull;
         acc[ty * S + tx] = a;
@@ -585,8 +594,13 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
     tyv[u] = i / inW;
     txv[u] = i - tyv[u] * inW;
     const int x = x0 - r + txv[u], y = y0 - r + tyv[u];
-    const unsigned v = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
-    sv[u] = (x >= 0 && x < w && y >= 0 && y < h) ? v : 0u;
+    sv[u] = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
+  }
+  GKLT_ISSUE_TOGETHER_12(sv);
+#pragma unroll
+  for (int u = 0; u < kStage; ++u) {
+    const int x = x0 - r + txv[u], y = y0 - r + tyv[u];
+    if (!(x >= 0 && x < w && y >= 0 && y < h)) sv[u] = 0u;
   }
   if (!any) {  // uniform over the workgroup
     if (threadIdx.x == 0) {
@@ -716,6 +730,278 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
     if (!ch || left_now == 0) break;
   }
   if (threadIdx.x == 0) {
+    *my_left = left_now;
+    cur_changed[tile] = (unsigned char)changed_ever;
+    if (left_now) atomicAdd(counter, left_now);
+  }
+}
+
+// ---- rounds on box tops: the plain selection and the uncapped phase of the Uniform selector
+// Accepted candidates are more than r apart in x or in y, so a (r+1) x (r+1) box of pixels holds at
+// most one of them, and the only candidate of a box that the rule can accept is the box's TOP: its
+// highest-priority undecided candidate (every other candidate of the box has that one inside its
+// window).  The dense rounds above evaluate the rule at every pixel; here a round evaluates it at
+// one pixel per box -- 17 K boxes instead of 2 M pixels at 1080p and r = 10 -- and the work of a
+// round shrinks with the number of boxes that are still open:
+//   * the state map keeps the invariant that a pixel covered by an accepted one is 0 (rejected):
+//     the wavefront that accepts a candidate zeroes its whole (2r+1)^2 window, in LDS and in the
+//     global map (also the part that lies in neighbouring tiles);
+//   * a workgroup stages its tile of boxes with a halo of r as 64-bit keys (0 = nothing to decide,
+//     all ones = accepted); per iteration every open box is taken by one wavefront: box maximum
+//     (two DPP reductions) -> top; window maximum > top -> the box waits; otherwise ACCEPT.  A box
+//     is closed once it holds an accepted pixel or no candidate.
+// Keys are built per tile: (priority field, score, tile row, tile column) orders any two pixels the
+// way the global priority does, and the low 16 bits of a box maximum are the position of the top.
+// Concurrency: every map entry goes score -> (0 | accepted) once and never changes again, and a
+// wavefront accepts only after it has read every entry of the window.  Two candidates within r of
+// each other are never both accepted -- the lower one sees the higher one undecided or accepted,
+// whatever the interleaving or the age of its halo copy -- so a stale copy only delays a decision,
+// as in the dense rounds, and the iterations of a tile need no barrier for their data (the one
+// barrier per iteration collects the progress flags).
+constexpr int kTopsW = 64, kTopsH = 32, kTopsT = 256;
+constexpr unsigned long long kOnes = ~0ull;
+struct TopsGeom {
+  int B, nbx, nby, cw, ch, inw, inh, S;
+};
+__host__ __device__ inline TopsGeom tops_geom(int r) {
+  TopsGeom g;
+  g.B = r + 1;
+  g.nbx = (kTopsW + g.B / 2) / g.B > 1 ? (kTopsW + g.B / 2) / g.B : 1;  // nearest to 64 x 32 pixels
+  g.nby = (kTopsH + g.B / 2) / g.B > 1 ? (kTopsH + g.B / 2) / g.B : 1;
+  g.cw = g.nbx * g.B;
+  g.ch = g.nby * g.B;
+  g.inw = g.cw + 2 * r;
+  g.inh = g.ch + 2 * r;
+  g.S = g.inw | 1;
+  return g;
+}
+inline size_t tops_lds_bytes(int r) {
+  const TopsGeom g = tops_geom(r);
+  return 8 * (size_t)g.inh * g.S + 2 * (size_t)(g.inw + g.inh);
+}
+// boxes of fewer than 5 x 5 pixels leave a wavefront mostly idle (and a tile would hold more boxes
+// than a wavefront's open-box mask has bits): those radii keep the dense rounds
+inline bool tops_usable(int r) {
+  const TopsGeom g = tops_geom(r);
+  return r >= 4 && g.inw <= 255 && g.inh <= 255 && tops_lds_bytes(r) <= 64 * 1024;
+}
+
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+// maximum over the 64 lanes, wave-uniform (full EXEC required)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = max(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = max(v, dpp_mov<0x124>(v));  // row_ror:4
+  v = max(v, dpp_mov<0x128>(v));  // row_ror:8 -> every lane holds the maximum of its row of 16
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned mh = wave_max_u32(hi);
+  const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
+template <int N, typename F>
+__device__ __forceinline__ void for_each(int n, F f) {
+  const int lane = threadIdx.x & 63;
+  if constexpr (N > 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) f(min(lane + 64 * k, n - 1));
+  } else {
+    for (int i0 = 0; i0 < n; i0 += 64) f(min(lane + i0, n - 1));
+  }
+}
+
+template <int R, bool UNI>
+__global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ state, int w, int h,
+                                                       int r_rt, unsigned *__restrict__ counters,
+                                                       unsigned *__restrict__ tile_left,
+                                                       const unsigned char *__restrict__ prev_changed,
+                                                       unsigned char *__restrict__ cur_changed,
+                                                       int gate, int max_local, int round,
+                                                       U32Grid ug) {
+  extern __shared__ __align__(16) unsigned long long ldsk[];
+  const int r = R >= 0 ? R : r_rt;
+  const TopsGeom G = tops_geom(r);
+  const int B = G.B, S = G.S, WW = 2 * r + 1;
+  unsigned long long *key = ldsk;  // inh x S
+  unsigned short *colcell = reinterpret_cast<unsigned short *>(key + G.inh * S);  // UNI: cell column of a tile column
+  unsigned short *rowcell = colcell + G.inw;                                      //      cell row of a tile row
+  __shared__ unsigned blk_left[3];
+  __shared__ int blk_changed[3];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int NW = kTopsT / 64;
+  unsigned *const counter = counters + round;
+  const int x0 = blockIdx.x * G.cw, y0 = blockIdx.y * G.ch;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  unsigned *const my_left = tile_left + tile;
+  const unsigned left_before = *my_left;  // open boxes after the tile's last launch
+  if (left_before == 0) {                 // closed tiles stay closed
+    if (tid == 0) cur_changed[tile] = 0;
+    return;
+  }
+  if (gate) {
+    int any = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int bx = min(max((int)blockIdx.x + dx, 0), (int)gridDim.x - 1);
+        const int by = min(max((int)blockIdx.y + dy, 0), (int)gridDim.y - 1);
+        any |= prev_changed[by * gridDim.x + bx];
+      }
+    if (!any) {  // uniform over the workgroup: same halo, same conclusions as last time
+      if (tid == 0) {
+        cur_changed[tile] = 0;
+        atomicAdd(counter, left_before);
+      }
+      return;
+    }
+  }
+  if (tid == 0) {
+    blk_left[0] = blk_left[1] = blk_left[2] = 0;
+    blk_changed[0] = blk_changed[1] = blk_changed[2] = 0;
+  }
+  // UNI: visiting ranks of the grid cells that meet the haloed tile, in LDS when they are few
+  constexpr int kCells = 64;
+  __shared__ unsigned short crank[kCells];
+  int cx0 = 0, cy0 = 0, ncx = 0;  // ncx == 0: too many cells, ranks are read from the global table
+  if constexpr (UNI) {
+    for (int t = tid; t < G.inw + G.inh; t += kTopsT) {
+      if (t < G.inw)
+        colcell[t] = (unsigned short)min(min(max(x0 - r + t, 0), w - 1) / ug.gw, ug.cw - 1);
+      else
+        rowcell[t - G.inw] = (unsigned short)min(min(max(y0 - r + t - G.inw, 0), h - 1) / ug.gh, ug.ch - 1);
+    }
+    __syncthreads();
+    cx0 = colcell[0];
+    cy0 = rowcell[0];
+    const int nx = colcell[G.inw - 1] - cx0 + 1, ny = rowcell[G.inh - 1] - cy0 + 1;
+    if (nx * ny <= kCells) {
+      ncx = nx;
+      if (tid < nx * ny) crank[tid] = ug.rank[(cy0 + tid / nx) * ug.cw + cx0 + tid % nx];
+    }
+    __syncthreads();
+  }
+  // staging in batches of unconditional (clamped) loads, so that a batch is in flight together
+  constexpr int kStage = 6;
+  static_assert(kStage == 6, "the asm statement below names six registers");
+  const int total = G.inw * G.inh;
+  for (int i0 = tid; i0 < total; i0 += kStage * kTopsT) {
+    unsigned sv[kStage];
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int i = min(i0 + u * kTopsT, total - 1);
+      const int ty = i / G.inw, tx = i - ty * G.inw;
+      const int x = x0 - r + tx, y = y0 - r + ty;
+      const unsigned v = state[(size_t)min(max(y, 0), h - 1) * w + min(max(x, 0), w - 1)];
+      sv[u] = v;
+    }
+    // all loads of the batch are issued before any is used: without this the compiler sinks each
+    // load into the in-image test below and waits for it there, one round trip per entry
+    asm volatile("" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]));
+#pragma unroll
+    for (int u = 0; u < kStage; ++u) {
+      const int i = i0 + u * kTopsT;
+      if (i < total) {
+        const int ty = i / G.inw, tx = i - ty * G.inw;
+        const int x = x0 - r + tx, y = y0 - r + ty;
+        const unsigned s = (x >= 0 && x < w && y >= 0 && y < h) ? sv[u] : 0u;
+        unsigned long long k = 0ull;
+        if (s & kAccepted) {
+          k = kOnes;
+        } else if (s != 0) {
+          unsigned fld = 0;
+          if constexpr (UNI)
+            fld = 0xFFFFu - (ncx ? crank[(rowcell[ty] - cy0) * ncx + colcell[tx] - cx0]
+                                 : ug.rank[rowcell[ty] * ug.cw + colcell[tx]]);
+          k = ((unsigned long long)fld << 48) | ((unsigned long long)s << 16) |
+              (unsigned long long)((0xFF - ty) << 8 | (0xFF - tx));
+        }
+        key[ty * S + tx] = k;
+      }
+    }
+  }
+  __syncthreads();
+  // f(i) for i = lane, lane + 64, ... below n, indices clamped to n - 1 (so that all loads of a pass
+  // are unconditional and in flight together); unrolled when the radius is a compile-time constant
+  constexpr int NBOX = R >= 0 ? ((R + 1) * (R + 1) + 63) / 64 : 0;
+  constexpr int NWIN = R >= 0 ? ((2 * R + 1) * (2 * R + 1) + 63) / 64 : 0;
+  const int nb = G.nbx * G.nby;
+  unsigned open = 0;  // bit j: box wave + j * NW is open (wave-uniform)
+  for (int j = 0; wave + j * NW < nb; ++j) {
+    // boxes that start outside the image hold nothing
+    const int b = wave + j * NW;
+    if (x0 + (b % G.nbx) * B < w && y0 + (b / G.nbx) * B < h) open |= 1u << j;
+  }
+  int changed_ever = 0;
+  unsigned left_now = 0;
+  for (int it = 0; it < max_local; ++it) {
+    const int pp = it % 3;
+    int accepted = 0;
+    for (int j = 0; wave + j * NW < nb; ++j) {
+      if (!(open >> j & 1)) continue;
+      const int b = wave + j * NW;
+      const int base = (r + (b / G.nbx) * B) * S + r + (b % G.nbx) * B;
+      unsigned long long m = 0ull;
+      for_each<NBOX>(B * B, [&](int i) {  // clamped index: a pixel read twice does not change a maximum
+        const int by = i / B;
+        m = max(m, key[base + by * S + i - by * B]);
+      });
+      m = wave_max_u64(m);
+      if (m == 0ull || m == kOnes) {  // no candidate left / holds an accepted pixel: closed
+        open &= ~(1u << j);
+        continue;
+      }
+      const int tx = 0xFF - (int)(m & 0xFF), ty = 0xFF - (int)((m >> 8) & 0xFF);
+      const int ctr = ty * S + tx;
+      bool higher = false;
+      for_each<NWIN>(WW * WW, [&](int i) {
+        const int wy = i / WW;
+        higher |= key[ctr + (wy - r) * S + (i - wy * WW - r)] > m;
+      });
+      if (__any(higher)) continue;  // a higher-priority candidate of the window is undecided, or an
+                                    // accepted one is about to reject this one: the box waits
+      const int cx = x0 - r + tx, cy = y0 - r + ty;
+      for_each<NWIN>(WW * WW, [&](int i) {  // the centre is written last, by lane 0 (it may be the
+        const int wy = i / WW, dy = wy - r, dx = i - wy * WW - r;  // clamped duplicate of another lane)
+        const int x = cx + dx, y = cy + dy;
+        if (dx != 0 || dy != 0) {
+          key[ctr + dy * S + dx] = 0ull;
+          if (x >= 0 && x < w && y >= 0 && y < h) state[(size_t)y * w + x] = 0u;
+        }
+      });
+      if (lane == 0) {
+        key[ctr] = kOnes;
+        state[(size_t)cy * w + cx] = (unsigned)((m >> 16) & 0x7FFFFFFFu) | kAccepted;
+      }
+      open &= ~(1u << j);
+      accepted = 1;
+    }
+    if (lane == 0) {
+      const unsigned left = __popc(open);
+      if (left) atomicAdd(&blk_left[pp], left);
+      if (accepted) blk_changed[pp] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {  // the slots of iteration it + 2 (= it - 1): last read before this barrier, next
+      const int q = (it + 2) % 3;  // written after the barrier of iteration it + 1
+      blk_left[q] = 0;
+      blk_changed[q] = 0;
+    }
+    left_now = blk_left[pp];
+    const int ch = blk_changed[pp];
+    changed_ever |= ch;
+    if (!ch || left_now == 0) break;
+  }
+  if (tid == 0) {
     *my_left = left_now;
     cur_changed[tile] = (unsigned char)changed_ever;
     if (left_now) atomicAdd(counter, left_now);
@@ -921,7 +1207,9 @@ void sel_free(SelScratch *s) {
 static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   SelScratch *s = ctx->sel;
   const size_t px = (size_t)w * h, sum = (size_t)(w + 1) * (h + 1);
-  const size_t tiles = (size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH);
+  // tiles of the dense rounds (64 x 16) or of the box rounds (at least 33 x 17), whichever are more
+  const size_t tiles = std::max((size_t)((w + MW - 1) / MW) * ((h + MH - 1) / MH),
+                                (size_t)((w + 32) / 33) * ((h + 16) / 17));
   if (s && (s->cap_px < px || s->cap_sum < sum || s->cap_tiles < tiles || s->cap_slots < nslots)) {
     GKLT_HIP(hipDeviceSynchronize());
     sel_free(s);
@@ -950,8 +1238,8 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   s->w = w;
   s->h = h;
   s->cap_list = (int)px;  // mindist 1 accepts every candidate
-  s->ntiles = tiles;
-  s->tile_bytes = sizeof(unsigned) * tiles;
+  s->ntiles = s->cap_tiles;  // the two halves of tile_changed lie cap_tiles apart
+  s->tile_bytes = sizeof(unsigned) * s->cap_tiles;
   *out = s;
   return 0;
 }
@@ -1007,21 +1295,31 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
 
   // fixpoint rounds (r < 0 happens for mindist 0: every candidate is accepted in one round)
   const int rr = std::max(r, 0);
-  // 32-bit keys by default; the 64-bit rounds shared with the Uniform selector stay selectable
-  const bool k32 = ctx->sel_impl == 0;
-  const size_t lds = k32 ? mis32_lds_bytes(rr) : mis_lds_bytes(rr);
+  // select impl 0: rounds on box tops where the radius allows them, else dense rounds on 32-bit
+  // keys; 1: dense rounds on the 64-bit keys shared with the Uniform selector; 2: dense, 32-bit
+  const bool tops = ctx->sel_impl == 0 && tops_usable(rr);
+  const bool k32 = !tops && ctx->sel_impl != 1;
+  const size_t lds = tops ? tops_lds_bytes(rr) : k32 ? mis32_lds_bytes(rr) : mis_lds_bytes(rr);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", P.mindist, lds);
     return GKLT_EINVAL;
   }
   // the radii of the reference's defaults (mindist 10: 9 plain, 10 for the ...2 / Uniform flavours)
   // are compiled in; any other radius runs the same code with r at run time
-  auto kern = k32 ? (rr == 9 ? k_mis32_round<9> : rr == 10 ? k_mis32_round<10> : k_mis32_round<-1>)
-                  : (rr == 9 ? k_mis_round<9> : rr == 10 ? k_mis_round<10> : k_mis_round<-1>);
+  auto kern = tops ? (rr == 9 ? k_tops_round<9, false> : rr == 10 ? k_tops_round<10, false> : k_tops_round<-1, false>)
+              : k32 ? (rr == 9 ? k_mis32_round<9> : rr == 10 ? k_mis32_round<10> : k_mis32_round<-1>)
+                    : (rr == 9 ? k_mis_round<9> : rr == 10 ? k_mis_round<10> : k_mis_round<-1>);
   if (lds > 48 * 1024)
     GKLT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH);
+  const TopsGeom tg = tops_geom(rr);
+  const dim3 grid = tops ? dim3((w + tg.cw - 1) / tg.cw, (h + tg.ch - 1) / tg.ch)
+                         : dim3((w + MW - 1) / MW, (h + MH - 1) / MH);
+  // a tile is skipped while neither it nor one of its 8 neighbours decided anything: valid only if
+  // nothing farther away can change what the tile sees (its halo of r; the box rounds also write
+  // up to r deep into the neighbouring tiles)
+  const int gate = tops ? (tg.cw >= 2 * rr && tg.ch >= 2 * rr) : (rr <= MH);
+  const int local_iters = tops ? ctx->sel_tops_iters : ctx->sel_local_iters;
   GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));
   GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
   int round = 1;
@@ -1037,7 +1335,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
       for (int b = 0; b < nbatch && round <= kMaxRounds; ++b, ++round)
         hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
                            sc->tile_left, sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
-                           sc->tile_changed + (round & 1) * sc->ntiles, 1, ctx->sel_local_iters,
+                           sc->tile_changed + (round & 1) * sc->ntiles, gate, local_iters,
                            round, U32Grid{});
     }
     GKLT_HIP(hipGetLastError());
@@ -1298,26 +1596,34 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
 // the accepted candidates), so that its result comes back with the poll that finds the rounds
 // converged instead of costing a host synchronisation of its own.  The poll also fetches the
 // need64 flag (h_counters[kPollNeed64]) and counters[0] (h_counters[kPollCount]).
+enum { kUniKeys64 = 0, kUniKeys32 = 1, kUniTops = 2 };  // round kernels of the uncapped phase
 static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
-                      UCaps caps, int r, int *round_io, bool keys32 = false,
+                      UCaps caps, int r, int *round_io, int keys = kUniKeys64,
                       const std::function<int()> &tail = {}) {
   const int w = sc->w, h = sc->h;
-  const size_t lds = keys32 ? mis32_lds_bytes(r) : mis_lds_bytes(r);
+  const bool keys32 = keys == kUniKeys32, tops = keys == kUniTops;
+  const size_t lds = tops ? tops_lds_bytes(r) : keys32 ? mis32_lds_bytes(r) : mis_lds_bytes(r);
   if (lds > 160 * 1024) {
     set_error("mindist %d needs %zu bytes of LDS per tile (> 160 KiB)", r, lds);
     return GKLT_EINVAL;
   }
   auto kern = r == 10 ? k_u_round<10> : k_u_round<-1>;
-  auto kern32 = r == 10 ? k_mis32_round<10, true> : k_mis32_round<-1, true>;
+  auto kern32 = tops ? (r == 10 ? k_tops_round<10, true> : k_tops_round<-1, true>)
+                     : (r == 10 ? k_mis32_round<10, true> : k_mis32_round<-1, true>);
   if (lds > 48 * 1024)
-    GKLT_HIP(hipFuncSetAttribute(keys32 ? reinterpret_cast<const void *>(kern32) : reinterpret_cast<const void *>(kern),
+    GKLT_HIP(hipFuncSetAttribute(keys32 || tops ? reinterpret_cast<const void *>(kern32) : reinterpret_cast<const void *>(kern),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const dim3 grid((w + MW - 1) / MW, (h + MH - 1) / MH), pgrid((w + 255) / 256, h);
+  const TopsGeom tg = tops_geom(r);
+  const dim3 grid = tops ? dim3((w + tg.cw - 1) / tg.cw, (h + tg.ch - 1) / tg.ch)
+                         : dim3((w + MW - 1) / MW, (h + MH - 1) / MH);
+  const dim3 pgrid((w + 255) / 256, h);
   GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));  // a phase starts: all tiles live
   GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
   // with caps a decision also depends on the cell's counters and maximum, which change without
   // any tile of the neighbourhood changing: no gating there
-  const int gate = caps.enabled ? 0 : 1;
+  // (and only where nothing beyond the 8 neighbouring tiles can change what a tile sees)
+  const int gate = caps.enabled ? 0 : tops ? (tg.cw >= 2 * r && tg.ch >= 2 * r) : (r <= MH);
+  const int local_iters = tops ? ctx->sel_tops_iters : ctx->sel_local_iters;
   const U32Grid ug{g.gw, g.gh, g.cw, g.ch, g.rank, u->flags + 2};
   const int phase = caps.enabled ? 1 : 0;
   int round = *round_io;
@@ -1337,12 +1643,12 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
         }
         unsigned char *const prev = sc->tile_changed + ((round - 1) & 1) * sc->ntiles;
         unsigned char *const cur = sc->tile_changed + (round & 1) * sc->ntiles;
-        if (keys32)
+        if (keys32 || tops)
           hipLaunchKernelGGL(kern32, grid, dim3(MT), lds, s, sc->state, w, h, r, sc->counters, sc->tile_left, prev,
-                             cur, gate, ctx->sel_local_iters, round, ug);
+                             cur, gate, local_iters, round, ug);
         else
           hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps, sc->counters,
-                             sc->tile_left, prev, cur, gate, ctx->sel_local_iters, round);
+                             sc->tile_left, prev, cur, gate, local_iters, round);
       }
     }
     GKLT_HIP(hipGetLastError());
@@ -1413,16 +1719,17 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   }
   const UGrid g{gridW, gridH, cw, ch, u->cellrank};
   const dim3 pgrid((w + 255) / 256, h);
-  const size_t px = (size_t)w * h;
-
   GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
-  {
+  // the candidates' scores; evaluated again (same bits) where a later step needs the initial map:
+  // a selection whose slots never run out -- every frame of a video after the first few -- then
+  // costs no copy of the map
+  auto score_into = [&](unsigned *dst) {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
     hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->sum[0], sc->sum[1], sc->sum[2],
                        (const unsigned char *)nullptr, w, h, hw, hh, bx, by, step,
-                       P.min_eigenvalue, 0, 0x7ffffffe, sc->state);
-  }
-  GKLT_HIP(hipMemcpyAsync(u->state0, sc->state, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
+                       P.min_eigenvalue, 0, 0x7ffffffe, dst);
+  };
+  score_into(sc->state);
 
   int round = 1;
   UCaps nocaps{0, 0, 0, 0, nullptr, nullptr};
@@ -1433,7 +1740,9 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   // centre-out order is 93 cells on the 60 x 33 grid of a 1080p frame, and a lone wavefront needs
   // several microseconds per cell: 12 ms, against 0.64 ms for these rounds.)
   const int tcx = (MW + 2 * r - 2) / gridW + 2, tcy = (MH + 2 * r - 2) / gridH + 2;
-  const bool keys32 = ctx->sel_impl != 1 && tcx * tcy <= kU32Cells;
+  const int keys = ctx->sel_impl == 0 && tops_usable(r) ? kUniTops
+                   : ctx->sel_impl != 1 && tcx * tcy <= kU32Cells ? kUniKeys32 : kUniKeys64;
+  const bool keys32 = keys == kUniKeys32;
   // The accepted candidates are collected behind every batch of rounds, so that their number
   // arrives with the poll that sees the rounds converged (one host synchronisation instead of
   // three: rounds, need64, count); the ranking needs the count for its grid and follows the poll.
@@ -1458,13 +1767,13 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     return 0;
   };
   GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
-  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys32, enqueue_collect)) return rc;
+  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys, enqueue_collect)) return rc;
   if (keys32 && sc->h_counters[kPollNeed64]) {
-    GKLT_HIP(hipMemcpyAsync(sc->state, u->state0, sizeof(unsigned) * px, hipMemcpyDeviceToDevice, s));
+    score_into(sc->state);
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
     GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
     round = 1;
-    if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, false, enqueue_collect)) return rc;
+    if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, kUniKeys64, enqueue_collect)) return rc;
   }
 
   unsigned nacc = sc->h_counters[kPollCount];
@@ -1485,12 +1794,13 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     const int cellT = std::min(ty / gridH, ch - 1) * cw + std::min(tx / gridW, cw - 1);
     UCaps caps{1, 0xFFFF - (int)(hT[0] >> 48), std::max(a1, minFeat + 1), minFeat + 1, u->cellmax,
                u->cellcount};
+    score_into(u->state0);
     hipLaunchKernelGGL(k_u_reset, pgrid, dim3(256), 0, s, sc->state, u->state0, w, h, g, u->tinfo);
     GKLT_HIP(hipMemsetAsync(u->cellcount, 0, sizeof(int) * ncell, s));
     GKLT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(u->cellcount + cellT), a1, 1, s));
     GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
     round = 1;
-    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round, false, enqueue_collect)) return rc;  // phase B
+    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round, kUniKeys64, enqueue_collect)) return rc;  // phase B
     nacc = sc->h_counters[kPollCount];
     if (int rc = enqueue_rank(nacc)) return rc;
     // is a grown slot left unfilled?  (see the comment at the top of this section)
@@ -1539,11 +1849,12 @@ using namespace gklt;
 extern "C" int gklt_ctx_set_select_iters(gklt_ctx *ctx, int iters) {
   if (!ctx || iters < 1 || iters > 64) return GKLT_EINVAL;
   ctx->sel_local_iters = iters;
+  ctx->sel_tops_iters = iters;
   return 0;
 }
 
 extern "C" int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl) {
-  if (!ctx || impl < 0 || impl > 1) return GKLT_EINVAL;
+  if (!ctx || impl < 0 || impl > 2) return GKLT_EINVAL;
   ctx->sel_impl = impl;
   return 0;
 }

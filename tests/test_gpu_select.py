@@ -190,10 +190,11 @@ def _checker_gradients(H, W, amp):
     return np.where(even, amp, 0).astype(np.float32), np.where(even, 0, amp).astype(np.float32)
 
 
-@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 6), (0, 64), (1, 1), (1, 6)])
+@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 6), (0, 64), (1, 1), (1, 6), (2, 1), (2, 6)])
 @pytest.mark.parametrize("case", ["texture", "saturated", "flat_ties"])
 def test_select_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case):
-    """32-bit and 64-bit rounds, any number of LDS iterations per launch: the same lists.
+    """Rounds on box tops (select impl 0), dense rounds on 64-bit (1) and 32-bit keys (2), any number
+    of LDS iterations per launch: the same lists.
     saturated: a block of INT_MAX scores (clamped, selectGoodFeatures.hpp:351-361) next to ordinary
     ones; flat_ties: every candidate has the same score, so positions alone decide."""
     H, W, n = 120, 200, 300
@@ -231,13 +232,13 @@ def test_select_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case):
     _same_lists(gotu, refu)
 
 
-@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 3), (0, 64), (1, 3)])
+@pytest.mark.parametrize("impl,iters", [(0, 1), (0, 3), (0, 64), (1, 3), (2, 1), (2, 3)])
 @pytest.mark.parametrize("case,grid", [("texture", (32, 32)), ("texture", (20, 20)), ("texture", (9, 9)),
                                        ("texture", (5, 7)), ("texture", (100, 90)),
                                        ("big_scores", (32, 32)), ("flat_ties", (32, 32)), ("flat_ties", (20, 24))])
 def test_uniform_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case, grid):
-    """Phase A of the Uniform selector on 32-bit keys (dense cell rank | 26-bit score; select impl 0)
-    and on 64-bit keys (impl 1): the oracle's lists either way.  big_scores: scores of 2^26 and more
+    """Phase A of the Uniform selector on box tops (select impl 0), on dense 64-bit keys (impl 1) and on
+    dense 32-bit keys (dense cell rank | 26-bit score; impl 2): the oracle's lists every way.  big_scores: scores of 2^26 and more
     do not fit the 32-bit keys, the phase is repeated on 64-bit keys; grids (9, 9) / (5, 7): a haloed
     tile meets more than 32 cells, 64-bit keys from the start; flat_ties: equal scores everywhere,
     so the cell order and, inside a cell, raster order decide."""
