@@ -758,10 +758,16 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
 // whatever the interleaving or the age of its halo copy -- so a stale copy only delays a decision,
 // as in the dense rounds, and the iterations of a tile need no barrier for their data (the one
 // barrier per iteration collects the progress flags).
+#ifdef GKLT_TOPS_BIG  // A/B builds (tools/build_timing.sh)
+constexpr int kTopsW = 128, kTopsH = 64, kTopsT = 1024;
+constexpr size_t kTopsMaxLds = 112 * 1024;
+#else
 constexpr int kTopsW = 64, kTopsH = 32, kTopsT = 256;
+constexpr size_t kTopsMaxLds = 64 * 1024;
+#endif
 constexpr unsigned long long kOnes = ~0ull;
 struct TopsGeom {
-  int B, nbx, nby, cw, ch, inw, inh, S;
+  int B, nbx, nby, cw, ch, inw, inh, ng, S;
 };
 __host__ __device__ inline TopsGeom tops_geom(int r) {
   TopsGeom g;
@@ -772,30 +778,31 @@ __host__ __device__ inline TopsGeom tops_geom(int r) {
   g.ch = g.nby * g.B;
   g.inw = g.cw + 2 * r;
   g.inh = g.ch + 2 * r;
-  g.S = g.inw | 1;
+  g.ng = (g.inw + 3) / 4;  // a row is staged in groups of four pixels
+  g.S = (4 * g.ng) | 1;
   return g;
 }
 inline size_t tops_lds_bytes(int r) {
   const TopsGeom g = tops_geom(r);
-  return 8 * (size_t)g.inh * g.S + 2 * (size_t)(g.inw + g.inh);
+  return 8 * (size_t)g.inh * g.S + 2 * (size_t)(4 * g.ng + g.inh);
 }
 // boxes of fewer than 5 x 5 pixels leave a wavefront mostly idle (and a tile would hold more boxes
 // than a wavefront's open-box mask has bits): those radii keep the dense rounds
 inline bool tops_usable(int r) {
   const TopsGeom g = tops_geom(r);
-  return r >= 4 && g.inw <= 255 && g.inh <= 255 && tops_lds_bytes(r) <= 64 * 1024;
+  return r >= 4 && g.inw <= 255 && g.inh <= 255 && tops_lds_bytes(r) <= kTopsMaxLds;
 }
 
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_mov(unsigned v) {
-  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-// maximum over the 64 lanes, wave-uniform (full EXEC required)
+// maximum over the 64 lanes, wave-uniform (full EXEC required).  The four row steps are written
+// as v_max_u32_dpp: from update_dpp + max the compiler emits mov, nop, mov_dpp, max per step.  A
+// DPP read of a VGPR the previous VALU instruction wrote needs two wait states (s_nop 1).
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-  v = max(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
-  v = max(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
-  v = max(v, dpp_mov<0x124>(v));  // row_ror:4
-  v = max(v, dpp_mov<0x128>(v));  // row_ror:8 -> every lane holds the maximum of its row of 16
+  asm("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"  // every lane now holds the maximum of its row of 16
+      : "+v"(v));
   const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
   const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
   return max(max(a, b), max(c, d));
@@ -818,6 +825,16 @@ __device__ __forceinline__ void for_each(int n, F f) {
   }
 }
 
+#ifdef GKLT_TOPS_TIMING
+// experiment builds only (tools/exp_tops_timing.py): per workgroup of the LAST launch, the shader
+// clock at entry, after staging, at exit, and the iterations it ran
+__device__ unsigned long long g_tops_dbg[4 * 8192];
+__device__ int g_tops_dbg_round = 1;
+#define TOPS_STAMP(k) if (threadIdx.x == 0 && tile < 8192 && round == g_tops_dbg_round) g_tops_dbg[4 * tile + (k)] = (k) == 3 ? (unsigned long long)its : wall_clock64()
+#else
+#define TOPS_STAMP(k)
+#endif
+
 template <int R, bool UNI>
 __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ state, int w, int h,
                                                        int r_rt, unsigned *__restrict__ counters,
@@ -832,7 +849,7 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
   const int B = G.B, S = G.S, WW = 2 * r + 1;
   unsigned long long *key = ldsk;  // inh x S
   unsigned short *colcell = reinterpret_cast<unsigned short *>(key + G.inh * S);  // UNI: cell column of a tile column
-  unsigned short *rowcell = colcell + G.inw;                                      //      cell row of a tile row
+  unsigned short *rowcell = colcell + 4 * G.ng;                                   //      cell row of a tile row
   __shared__ unsigned blk_left[3];
   __shared__ int blk_changed[3];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -842,6 +859,11 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
   const int x0 = blockIdx.x * G.cw, y0 = blockIdx.y * G.ch;
   const int tile = blockIdx.y * gridDim.x + blockIdx.x;
   unsigned *const my_left = tile_left + tile;
+  [[maybe_unused]] int its = 0;
+  TOPS_STAMP(0);
+  TOPS_STAMP(1);
+  TOPS_STAMP(2);
+  TOPS_STAMP(3);
   const unsigned left_before = *my_left;  // open boxes after the tile's last launch
   if (left_before == 0) {                 // closed tiles stay closed
     if (tid == 0) cur_changed[tile] = 0;
@@ -874,26 +896,79 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
   __shared__ unsigned short crank[kCells];
   int cx0 = 0, cy0 = 0, ncx = 0;  // ncx == 0: too many cells, ranks are read from the global table
   if constexpr (UNI) {
-    for (int t = tid; t < G.inw + G.inh; t += kTopsT) {
-      if (t < G.inw)
+    const int ncol = 4 * G.ng;
+    for (int t = tid; t < ncol + G.inh; t += kTopsT) {
+      if (t < ncol)
         colcell[t] = (unsigned short)min(min(max(x0 - r + t, 0), w - 1) / ug.gw, ug.cw - 1);
       else
-        rowcell[t - G.inw] = (unsigned short)min(min(max(y0 - r + t - G.inw, 0), h - 1) / ug.gh, ug.ch - 1);
+        rowcell[t - ncol] = (unsigned short)min(min(max(y0 - r + t - ncol, 0), h - 1) / ug.gh, ug.ch - 1);
     }
     __syncthreads();
     cx0 = colcell[0];
     cy0 = rowcell[0];
-    const int nx = colcell[G.inw - 1] - cx0 + 1, ny = rowcell[G.inh - 1] - cy0 + 1;
+    const int nx = colcell[ncol - 1] - cx0 + 1, ny = rowcell[G.inh - 1] - cy0 + 1;
     if (nx * ny <= kCells) {
       ncx = nx;
       if (tid < nx * ny) crank[tid] = ug.rank[(cy0 + tid / nx) * ug.cw + cx0 + tid % nx];
     }
     __syncthreads();
   }
-  // staging in batches of unconditional (clamped) loads, so that a batch is in flight together
+  // key of an undecided candidate with score sc at tile position (tx, ty); rowbase: see below
+  auto make_key = [&](unsigned sc, int tx, int ty, int rowbase) -> unsigned long long {
+    unsigned fld = 0;
+    if constexpr (UNI)
+      fld = 0xFFFFu - (ncx ? crank[rowbase + colcell[tx]] : ug.rank[rowcell[ty] * ug.cw + colcell[tx]]);
+    return ((unsigned long long)fld << 48) | ((unsigned long long)sc << 16) |
+           (unsigned long long)((0xFF - ty) << 8 | (0xFF - tx));
+  };
+  // Staging.  A tile whose staged columns (rounded up to whole groups) lie inside the image loads
+  // four pixels per load, all loads of a thread in flight together; the others (left and right
+  // image border) load pixel by pixel with clamped addresses.
+  const bool wide = x0 - r >= 0 && x0 - r + 4 * G.ng <= w;
+  if (wide) {
+    struct __attribute__((packed, aligned(4))) Quad { unsigned v[4]; };
+    constexpr int kG = 5;
+    const int ngroups = G.ng * G.inh;
+    for (int g0 = tid; g0 < ngroups; g0 += kG * kTopsT) {
+      Quad q[kG];
+#pragma unroll
+      for (int u = 0; u < kG; ++u) {
+        const int g = min(g0 + u * kTopsT, ngroups - 1);
+        const int ty = g / G.ng, gx = g - ty * G.ng;
+        const int y = min(max(y0 - r + ty, 0), h - 1);
+        q[u] = *reinterpret_cast<const Quad *>(state + (size_t)y * w + (x0 - r + 4 * gx));
+      }
+      asm volatile("" : "+v"(q[0].v[0]), "+v"(q[0].v[1]), "+v"(q[0].v[2]), "+v"(q[0].v[3]),
+                        "+v"(q[1].v[0]), "+v"(q[1].v[1]), "+v"(q[1].v[2]), "+v"(q[1].v[3]),
+                        "+v"(q[2].v[0]), "+v"(q[2].v[1]), "+v"(q[2].v[2]), "+v"(q[2].v[3]),
+                        "+v"(q[3].v[0]), "+v"(q[3].v[1]), "+v"(q[3].v[2]), "+v"(q[3].v[3]),
+                        "+v"(q[4].v[0]), "+v"(q[4].v[1]), "+v"(q[4].v[2]), "+v"(q[4].v[3]));
+#pragma unroll
+      for (int u = 0; u < kG; ++u) {
+        const int g = g0 + u * kTopsT;
+        if (g < ngroups) {
+          const int ty = g / G.ng, gx = g - ty * G.ng;
+          const int y = y0 - r + ty;
+          const bool yin = y >= 0 && y < h;
+          int rowbase = 0;
+          if constexpr (UNI) rowbase = (rowcell[ty] - cy0) * ncx - cx0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // columns inw .. 4 ng - 1 are staged too and never read
+            const int tx = 4 * gx + k;
+            const unsigned sv = yin ? q[u].v[k] : 0u;
+            unsigned long long kk = 0ull;
+            if (sv & kAccepted) kk = kOnes;
+            else if (sv != 0) kk = make_key(sv, tx, ty, rowbase);
+            key[ty * S + tx] = kk;
+          }
+        }
+      }
+    }
+  }
+  // in batches of unconditional (clamped) loads, so that a batch is in flight together
   constexpr int kStage = 6;
   static_assert(kStage == 6, "the asm statement below names six registers");
-  const int total = G.inw * G.inh;
+  const int total = wide ? 0 : G.inw * G.inh;
   for (int i0 = tid; i0 < total; i0 += kStage * kTopsT) {
     unsigned sv[kStage];
 #pragma unroll
@@ -918,18 +993,16 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
         if (s & kAccepted) {
           k = kOnes;
         } else if (s != 0) {
-          unsigned fld = 0;
-          if constexpr (UNI)
-            fld = 0xFFFFu - (ncx ? crank[(rowcell[ty] - cy0) * ncx + colcell[tx] - cx0]
-                                 : ug.rank[rowcell[ty] * ug.cw + colcell[tx]]);
-          k = ((unsigned long long)fld << 48) | ((unsigned long long)s << 16) |
-              (unsigned long long)((0xFF - ty) << 8 | (0xFF - tx));
+          int rowbase = 0;
+          if constexpr (UNI) rowbase = (rowcell[ty] - cy0) * ncx - cx0;
+          k = make_key(s, tx, ty, rowbase);
         }
         key[ty * S + tx] = k;
       }
     }
   }
   __syncthreads();
+  TOPS_STAMP(1);
   // f(i) for i = lane, lane + 64, ... below n, indices clamped to n - 1 (so that all loads of a pass
   // are unconditional and in flight together); unrolled when the radius is a compile-time constant
   constexpr int NBOX = R >= 0 ? ((R + 1) * (R + 1) + 63) / 64 : 0;
@@ -999,8 +1072,11 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
     left_now = blk_left[pp];
     const int ch = blk_changed[pp];
     changed_ever |= ch;
+    its = it + 1;
     if (!ch || left_now == 0) break;
   }
+  TOPS_STAMP(2);
+  TOPS_STAMP(3);
   if (tid == 0) {
     *my_left = left_now;
     cur_changed[tile] = (unsigned char)changed_ever;
@@ -1333,7 +1409,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
       const int nbatch = first == 1 && sc->last_rounds[0] > 0
                              ? std::min(std::max(sc->last_rounds[0] + 2, 4), kRoundBatch) : kRoundBatch;
       for (int b = 0; b < nbatch && round <= kMaxRounds; ++b, ++round)
-        hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, rr, sc->counters,
+        hipLaunchKernelGGL(kern, grid, dim3(tops ? kTopsT : MT), lds, s, sc->state, w, h, rr, sc->counters,
                            sc->tile_left, sc->tile_changed + ((round - 1) & 1) * sc->ntiles,
                            sc->tile_changed + (round & 1) * sc->ntiles, gate, local_iters,
                            round, U32Grid{});
@@ -1644,7 +1720,7 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
         unsigned char *const prev = sc->tile_changed + ((round - 1) & 1) * sc->ntiles;
         unsigned char *const cur = sc->tile_changed + (round & 1) * sc->ntiles;
         if (keys32 || tops)
-          hipLaunchKernelGGL(kern32, grid, dim3(MT), lds, s, sc->state, w, h, r, sc->counters, sc->tile_left, prev,
+          hipLaunchKernelGGL(kern32, grid, dim3(tops ? kTopsT : MT), lds, s, sc->state, w, h, r, sc->counters, sc->tile_left, prev,
                              cur, gate, local_iters, round, ug);
         else
           hipLaunchKernelGGL(kern, grid, dim3(MT), lds, s, sc->state, w, h, r, g, caps, sc->counters,
@@ -2051,3 +2127,15 @@ extern "C" int gklt_seed_from_level(gklt_ctx *ctx, gklt_pyramid *py, int level, 
   py->has_consumed = true;
   return 0;
 }
+
+#ifdef GKLT_TOPS_TIMING
+extern "C" int gklt_debug_tops_round(int round) {
+  GKLT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gklt::g_tops_dbg_round), &round, sizeof(int)));
+  return 0;
+}
+extern "C" int gklt_debug_tops_timing(unsigned long long *out, int n) {
+  GKLT_HIP(hipDeviceSynchronize());
+  GKLT_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(gklt::g_tops_dbg), sizeof(unsigned long long) * (size_t)n));
+  return 0;
+}
+#endif
