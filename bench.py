@@ -75,6 +75,7 @@ def parse(argv=None):
                          "legs launch the same kernels with one frame per launch)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive legs")
+    ap.add_argument("--no-shim", action="store_true", help="skip the shim_drop_in block")
     ap.add_argument("--select-variant", default="uniform", choices=["uniform", "plain", "round2"],
                     help="--config C5: selector flavour run every frame")
     ap.add_argument("--dry-launch", action="store_true",
@@ -524,6 +525,50 @@ def main_multistream(a, ctx, cfg, gp, dist, rank, world):
         dist.destroy_process_group()
 
 
+def shim_drop_in(frames, steps=256, warmup=16):
+    """The path an unchanged GSLAM gets (north_star: "System code calls it unchanged through a thin
+    C-ABI layer"): shim/gklt_shim.cpp's computePyramid on a preload std::thread + KLTTrackFeatures per
+    frame, the loop of System.cpp:501-518, frames in PAGEABLE host memory, AoS KLT_FeatureList,
+    bearing vectors included -- timed inside tests/shim_mock/shim_driver.cpp (drv_track_stream), no
+    Python in the loop.  C2 and as-shipped (Cship) parameters on the same 1080p frames."""
+    import ctypes as C
+
+    from gslam_amd import build as b
+
+    if not os.path.exists(b.SHIM_TEST_LIB):
+        return {"error": "%s not built (python gslam_amd/build.py)" % b.SHIM_TEST_LIB}
+    drv = C.CDLL(b.SHIM_TEST_LIB)
+    H, W = frames[0].shape
+    stack = np.ascontiguousarray(np.stack(frames))
+    invK = np.linalg.inv(np.array([[1400.0, 0, W / 2], [0, 1400.0, H / 2], [0, 0, 1]]))
+    dp, fp, ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int)
+    res = {}
+    for name in ("C2", "Cship"):
+        cfg = synth.CONFIGS[name]
+        if (cfg["H"], cfg["W"]) != (H, W):
+            continue
+        n = cfg["n"]
+        p = klt.make_params(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
+        sx, sy = synth.lattice_seeds(H, W, n, p.borderx, nx=cfg["lattice"][0], ny=cfg["lattice"][1])
+        out = np.zeros(4)
+        x, y, v = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+        rc = drv.drv_track_stream(W, H, len(frames), stack.ctypes.data_as(C.POINTER(C.c_uint8)), cfg["window"],
+                                  cfg["levels"], cfg.get("border", -1) or -1, n, sx.ctypes.data_as(fp),
+                                  sy.ctypes.data_as(fp), RESEED_EVERY, warmup, steps, invK.ctypes.data_as(dp),
+                                  out.ctypes.data_as(dp), x.ctypes.data_as(fp), y.ctypes.data_as(fp),
+                                  v.ctypes.data_as(ip))
+        if rc:
+            res[name] = {"error": "drv_track_stream rc=%d" % rc}
+            continue
+        res[name] = {"value": out[1] / out[0], "unit": "tracked_features*frames/s", "ms_per_frame": out[0] / steps * 1e3,
+                     "frames_per_s": steps / out[0], "p50_ms": out[2], "p99_ms": out[3], "steps": steps,
+                     "tracked_fraction": out[1] / (steps * n)}
+    res["mode"] = ("shim/gklt_shim.cpp: computePyramid (pageable cv::Mat frame -> staged H2D -> build -> coarsest "
+                   "plane back to the host) on a preload std::thread, KLTTrackFeatures (AoS list <-> gklt_track, fp64 "
+                   "bearing vectors) on the calling thread; C++ loop, wall clock around `steps` frames")
+    return res
+
+
 def c5_params(cfg):
     sel = cfg["select"]
     kw = dict(window=cfg["window"], levels=cfg["levels"], min_eigenvalue=sel["min_eigenvalue"],
@@ -830,6 +875,10 @@ def main(argv=None):
     tracked1, dt1, k1 = fa1
     lat, lat_full = np.array(lat), np.array(lat_full)
 
+    shim = None
+    if rank == 0 and world == 1 and not a.main_only and not a.no_shim:
+        shim = shim_drop_in(frames[:16], steps=min(max(a.steps, 64), 512))
+
     b_pyr, foot, px = algorithmic_bytes(cfg)
     per_kernel = {k: {"avg_us": ms / cnt * 1e3, "launches": cnt, "total_ms": ms}
                   for k, (ms, cnt) in prof.items() if cnt}
@@ -908,6 +957,7 @@ def main(argv=None):
                              "rocprofv3 --pmc passes in profiles/ (16-frame launches) x frames_per_launch, "
                              "null for other launch sizes; see DESIGN.md 4" % (p_iters / psteps / n)},
         "pcie_inclusive": pcie,
+        "shim_drop_in": shim,
         "kernels": per_kernel,
         "pyramid_algorithmic_bytes_per_frame": b_pyr,
     }

@@ -72,6 +72,43 @@ static int ensure_nv(gklt_ctx *ctx, int n) {
 
 int ensure_bearing_buffers(gklt_ctx *ctx, int n) { return ensure_nv(ctx, n); }
 
+int stage_reserve(HostStage *st, size_t bytes) {
+  if (st->pending) {
+    GKLT_HIP(hipEventSynchronize(st->done));
+    st->pending = false;
+  }
+  if (st->bytes >= bytes) return 0;
+  if (st->p) (void)hipHostFree(st->p);
+  st->p = nullptr;
+  st->bytes = 0;
+  if (!st->done) GKLT_HIP(hipEventCreateWithFlags(&st->done, hipEventDisableTiming));
+  const size_t want = std::max(bytes + bytes / 4, (size_t)1 << 16);
+  GKLT_HIP(hipHostMalloc(&st->p, want, hipHostMallocDefault));
+  st->bytes = want;
+  return 0;
+}
+
+int stage_mark(HostStage *st, hipStream_t s) {
+  GKLT_HIP(hipEventRecord(st->done, s));
+  st->pending = true;
+  return 0;
+}
+
+void stage_free(HostStage *st) {
+  if (st->p) (void)hipHostFree(st->p);
+  if (st->done) (void)hipEventDestroy(st->done);
+  *st = HostStage{};
+}
+
+bool host_is_pinned(const void *p) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();  // an unregistered pointer is an error on some runtimes: not ours
+    return false;
+  }
+  return a.type == hipMemoryTypeHost;
+}
+
 static int check_params(const gklt_params &p) {
   if (p.nPyramidLevels < 1 || p.nPyramidLevels > GKLT_MAX_LEVELS) {
     set_error("nPyramidLevels %d outside [1,%d]", p.nPyramidLevels, GKLT_MAX_LEVELS);
@@ -152,6 +189,10 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
   sel_free(ctx->sel);
   ransac_free(ctx->ransac);
+  for (auto &st : ctx->stage_frame) stage_free(&st);
+  stage_free(&ctx->stage_plane);
+  stage_free(&ctx->stage_trk);
+  (void)hipFree(ctx->d_trk);
   (void)hipFree(ctx->d_frame);
   (void)hipFree(ctx->d_invk);
   (void)hipFree(ctx->d_norm);
@@ -168,7 +209,13 @@ extern "C" int gklt_ctx_set_params(gklt_ctx *ctx, const gklt_params *p) {
   gklt_params q = *p;
   fix_window(&q);  // LK.hpp:982-1013 warn-and-fix (the shim prints the KLTWarning)
   if (int rc = check_params(q)) return rc;
-  ctx->prm = q;
+  // GSLAM pushes its tracking context on every call, from the preload thread (computePyramid) and
+  // from the main thread (KLTTrackFeatures) at the same time (System.cpp:326-344,508-518), with the
+  // same values: an unchanged block is not written, so the calls of the other thread, which read
+  // ctx->prm, see no write at all.  (Changing parameters while a call is in flight on another
+  // thread is a race in the reference as well.)
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (std::memcmp(&ctx->prm, &q, sizeof q) != 0) ctx->prm = q;
   return 0;
 }
 
@@ -286,13 +333,30 @@ extern "C" int gklt_pyramid_build(gklt_ctx *ctx, gklt_pyramid *py, const uint8_t
       GKLT_HIP(hipMalloc(&ctx->d_frame, bytes));
       ctx->d_frame_bytes = bytes;
     }
-    GKLT_HIP(copy_plane_h2d(ctx->d_frame, img, stride, W, H, s));
+    if (host_is_pinned(img)) {
+      GKLT_HIP(copy_plane_h2d(ctx->d_frame, img, stride, W, H, s));
+    } else {
+      // pageable frame (a cv::Mat): through one of two page-locked blocks, so that the caller's
+      // frame is free when the call returns and the H2D copy is one DMA transfer
+      HostStage *st = &ctx->stage_frame[ctx->stage_frame_next];
+      ctx->stage_frame_next ^= 1;
+      if (int rc = stage_reserve(st, bytes)) return rc;
+      uint8_t *hp = static_cast<uint8_t *>(st->p);
+      if (stride == W) {
+        std::memcpy(hp, img, bytes);
+      } else {
+        for (int r = 0; r < H; ++r) std::memcpy(hp + (size_t)r * W, img + (size_t)r * stride, W);
+      }
+      GKLT_HIP(copy_plane_h2d(ctx->d_frame, hp, W, W, H, s));
+      if (int rc = stage_mark(st, s)) return rc;
+    }
     src = ctx->d_frame;
     src_stride = W;
   }
   if (int rc = enqueue_build(ctx, s, py, src, src_stride)) return rc;
   GKLT_HIP(hipEventRecord(py->ready, s));
   py->has_ready = true;
+  py->built_on_pyr = true;
   return 0;
 }
 
@@ -430,13 +494,24 @@ extern "C" int gklt_pyramid_download(gklt_ctx *ctx, gklt_pyramid *py, int level,
   if (dst_stride < L.w) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   hipStream_t s = ctx->s_pyr;
-  // every plane comes out of the texels: the fused build never writes level 0's planar image
-  GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  // every plane comes out of the texels: the fused build never writes level 0's planar image.
+  // A pyramid built by gklt_pyramid_build is complete in stream order (same stream); the pipeline
+  // objects build on either stream, so their pyramids are waited for on the host.
+  if (!py->built_on_pyr) GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
   if (int rc = launch_tex_extract(ctx, s, L.tex, L.w * L.h, plane, py->tmp)) return rc;
-  const float *src = py->tmp;
-  GKLT_HIP(hipMemcpy2DAsync(dst, sizeof(float) * dst_stride, src, sizeof(float) * L.w,
-                            sizeof(float) * L.w, L.h, hipMemcpyDeviceToHost, s));
+  const size_t row = sizeof(float) * (size_t)L.w;
+  if (host_is_pinned(dst)) {
+    GKLT_HIP(hipMemcpy2DAsync(dst, sizeof(float) * dst_stride, py->tmp, row, row, L.h, hipMemcpyDeviceToHost, s));
+    GKLT_HIP(hipStreamSynchronize(s));
+    return 0;
+  }
+  // pageable destination: one dense transfer into page-locked memory, rows copied on the host
+  HostStage *st = &ctx->stage_plane;
+  if (int rc = stage_reserve(st, row * L.h)) return rc;
+  GKLT_HIP(hipMemcpyAsync(st->p, py->tmp, row * L.h, hipMemcpyDeviceToHost, s));
   GKLT_HIP(hipStreamSynchronize(s));
+  const char *hp = static_cast<const char *>(st->p);
+  for (int r = 0; r < L.h; ++r) std::memcpy(dst + (size_t)r * dst_stride, hp + (size_t)r * row, row);
   return 0;
 }
 
@@ -472,7 +547,7 @@ extern "C" int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *py, int level, i
   GKLT_HIP(hipEventRecord(py->ready, s));
   py->has_ready = true;
   GKLT_HIP(hipStreamSynchronize(s));
-  return 0;
+  return 0;  // (built_on_pyr keeps its value: the other planes are as old as they were)
 }
 
 // standalone P1 / P2 on host images
@@ -696,33 +771,53 @@ extern "C" int gklt_track(gklt_ctx *ctx, gklt_pyramid *p1, gklt_pyramid *p2, int
   if (n == 0) return 0;
   if (!x || !y || !val) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
-  if (!ctx->scratch_list || ctx->scratch_list->capacity < n) {
-    if (ctx->scratch_list) gklt_flist_destroy(ctx->scratch_list);
-    ctx->scratch_list = nullptr;
-    if (int rc = gklt_flist_create(ctx, std::max(n, 4096), &ctx->scratch_list)) return rc;
-  }
-  gklt_flist *fl = ctx->scratch_list;
   hipStream_t s = ctx->s_trk;
-  if (int rc = gklt_flist_upload(ctx, fl, n, x, y, val)) return rc;
   const bool epi = invK && norm3 && vec3;
-  if (epi) {
-    if (int rc = ensure_nv(ctx, n)) return rc;
-    GKLT_HIP(hipMemcpyAsync(ctx->d_invk, invK, 9 * sizeof(double), hipMemcpyHostToDevice, s));
-    // untracked entries keep the caller's contents: round-trip them
-    GKLT_HIP(hipMemcpyAsync(ctx->d_norm, norm3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
-    GKLT_HIP(hipMemcpyAsync(ctx->d_vec, vec3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, s));
+  // One page-locked block and its device image, [x | y | val | invK | norm | vec]: the caller's
+  // arrays (pageable as a rule: the shim's std::vectors) cost ONE H2D transfer of the first four
+  // parts and ONE D2H transfer of the whole block, instead of ten pageable copies.
+  const size_t nn = (size_t)n;
+  const size_t o_k = (3 * sizeof(float) * nn + 7) / 8 * 8, o_norm = o_k + 9 * sizeof(double);
+  const size_t o_vec = o_norm + 3 * sizeof(double) * nn, total = o_vec + 3 * sizeof(double) * nn;
+  const size_t down = epi ? total : 3 * sizeof(float) * nn;
+  HostStage *st = &ctx->stage_trk;
+  if (int rc = stage_reserve(st, total)) return rc;
+  if (ctx->d_trk_bytes < total) {
+    GKLT_HIP(hipStreamSynchronize(s));
+    if (ctx->d_trk) (void)hipFree(ctx->d_trk);
+    ctx->d_trk = nullptr;
+    ctx->d_trk_bytes = 0;
+    const size_t want = total + total / 4;
+    GKLT_HIP(hipMalloc(&ctx->d_trk, want));
+    ctx->d_trk_bytes = want;
   }
-  if (int rc = track_common(ctx, p1, p2, n, fl->x, fl->y, fl->val, epi ? ctx->d_invk : nullptr,
-                            epi ? ctx->d_norm : nullptr, epi ? ctx->d_vec : nullptr, nullptr))
+  char *hp = static_cast<char *>(st->p), *dp = static_cast<char *>(ctx->d_trk);
+  std::memcpy(hp, x, sizeof(float) * nn);
+  std::memcpy(hp + sizeof(float) * nn, y, sizeof(float) * nn);
+  std::memcpy(hp + 2 * sizeof(float) * nn, val, sizeof(int) * nn);
+  if (epi) std::memcpy(hp + o_k, invK, 9 * sizeof(double));
+  GKLT_HIP(hipMemcpyAsync(dp, hp, epi ? o_norm : 3 * sizeof(float) * nn, hipMemcpyHostToDevice, s));
+  float *dx = reinterpret_cast<float *>(dp), *dy = dx + nn;
+  int *dv = reinterpret_cast<int *>(dy + nn);
+  double *d_k = reinterpret_cast<double *>(dp + o_k), *d_norm = reinterpret_cast<double *>(dp + o_norm);
+  double *d_vec = reinterpret_cast<double *>(dp + o_vec);
+  if (int rc = track_common(ctx, p1, p2, n, dx, dy, dv, epi ? d_k : nullptr, epi ? d_norm : nullptr,
+                            epi ? d_vec : nullptr, nullptr))
     return rc;
-  GKLT_HIP(hipMemcpyAsync(x, fl->x, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  GKLT_HIP(hipMemcpyAsync(y, fl->y, sizeof(float) * n, hipMemcpyDeviceToHost, s));
-  GKLT_HIP(hipMemcpyAsync(val, fl->val, sizeof(int) * n, hipMemcpyDeviceToHost, s));
-  if (epi) {
-    GKLT_HIP(hipMemcpyAsync(norm3, ctx->d_norm, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipMemcpyAsync(vec3, ctx->d_vec, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, s));
-  }
+  GKLT_HIP(hipMemcpyAsync(hp, dp, down, hipMemcpyDeviceToHost, s));
   GKLT_HIP(hipStreamSynchronize(s));
+  std::memcpy(x, hp, sizeof(float) * nn);
+  std::memcpy(y, hp + sizeof(float) * nn, sizeof(float) * nn);
+  std::memcpy(val, hp + 2 * sizeof(float) * nn, sizeof(int) * nn);
+  if (epi) {  // the tracker writes norm / vec of tracked features only (LK.hpp:1019-1035): the
+    const double *hn = reinterpret_cast<const double *>(hp + o_norm);  // others keep the caller's
+    const double *hv = reinterpret_cast<const double *>(hp + o_vec);
+    for (size_t i = 0; i < nn; ++i)
+      if (val[i] == GKLT_TRACKED) {
+        std::memcpy(norm3 + 3 * i, hn + 3 * i, 3 * sizeof(double));
+        std::memcpy(vec3 + 3 * i, hv + 3 * i, 3 * sizeof(double));
+      }
+  }
   return 0;
 }
 

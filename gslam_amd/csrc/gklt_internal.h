@@ -57,6 +57,24 @@ struct RansacScratch;  // outlier-rejection scratch (gklt_ransac.hip)
 void ransac_free(RansacScratch *r);
 }  // namespace gklt
 
+namespace gklt {
+// A page-locked staging block that ONE host thread / stream uses: host arrays of unknown provenance
+// (pageable cv::Mat frames, std::vector lists) are copied through it, because the runtime moves
+// pageable memory in small synchronous pieces (a 2-D copy of a pageable 1080p frame: 10 ms, row by
+// row; the same bytes from page-locked memory: 55 us).  `done` marks the last copy that read or
+// wrote the block.
+struct HostStage {
+  void *p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t done = nullptr;
+  bool pending = false;
+};
+int stage_reserve(HostStage *st, size_t bytes);  // waits for the pending copy, grows the block
+int stage_mark(HostStage *st, hipStream_t s);    // records `done` behind the copies just enqueued
+void stage_free(HostStage *st);
+bool host_is_pinned(const void *p);              // page-locked / registered host memory?
+}  // namespace gklt
+
 struct gklt_ctx {
   int device = 0;
   gklt::SelScratch *sel = nullptr;
@@ -67,6 +85,12 @@ struct gklt_ctx {
   // staging for host frames / host feature lists (grown on demand)
   uint8_t *d_frame = nullptr;
   size_t d_frame_bytes = 0;
+  gklt::HostStage stage_frame[2];  // pageable frames on their way to d_frame (builds, s_pyr's thread)
+  int stage_frame_next = 0;
+  gklt::HostStage stage_plane;     // plane downloads (s_pyr's thread)
+  gklt::HostStage stage_trk;       // gklt_track's list, invK and bearing vectors (s_trk's thread)
+  void *d_trk = nullptr;           // device image of stage_trk
+  size_t d_trk_bytes = 0;
   gklt_flist *scratch_list = nullptr;
   double *d_invk = nullptr;  // 9 doubles
   double *d_norm = nullptr, *d_vec = nullptr;
@@ -101,6 +125,7 @@ struct gklt_pyramid {
   hipEvent_t ready = nullptr;     // recorded on s_pyr after a build
   hipEvent_t consumed = nullptr;  // recorded on s_trk after a tracker launch that read it
   bool has_ready = false, has_consumed = false;
+  bool built_on_pyr = false;  // last written by gklt_pyramid_build / _upload, i.e. on s_pyr
 };
 
 struct gklt_flist {

@@ -117,6 +117,8 @@ void warn_and_fix_window(KLT_TrackingContext tc, const char *who) {
 }
 
 // System.cpp:326-344 rewrites tc every frame: the context follows it on every call
+// (gklt_ctx_set_params writes nothing when the block is unchanged, so the preload thread and the
+// main thread, which push the same values at the same time, do not race)
 gklt_ctx *push(KLT_TrackingContext tc) {
   gklt_ctx *ctx = context();
   const gklt_params p = to_params(tc);
@@ -288,9 +290,14 @@ void KLTTrackFeatures(KLT_TrackingContext tc, std::vector<cv::Mat> &pyramid1, st
   warn_and_fix_window(tc, "KLTTrackFeatures");  // LK.hpp:982-1013
   gklt_ctx *ctx = push(tc);
   const int n = fl->nFeatures;
-  std::vector<float> x(n), y(n);
-  std::vector<int> v(n);
-  std::vector<double> nrm(3 * (size_t)n), vec(3 * (size_t)n);
+  // SoA images of the list, kept from call to call (the list has the same size every frame)
+  static thread_local std::vector<float> x, y;
+  static thread_local std::vector<int> v;
+  static thread_local std::vector<double> nrm, vec;
+  if ((int)x.size() < n) {
+    x.resize(n); y.resize(n); v.resize(n);
+    nrm.resize(3 * (size_t)n); vec.resize(3 * (size_t)n);
+  }
   for (int i = 0; i < n; ++i) {  // AoS -> SoA; index i is the feature's identity and never moves
     const KLT_Feature f = fl->feature[i];
     x[i] = f->x;

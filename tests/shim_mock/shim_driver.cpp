@@ -1,8 +1,12 @@
 // Test driver: calls GSLAM's KLT host API (as implemented by shim/gklt_shim.cpp) the way System
 // does, behind a few extern "C" functions that tests/test_shim.py reaches through ctypes.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
+#include <vector>
 
 #include "KLTUtil.h"
 #include "LK.hpp"
@@ -136,6 +140,81 @@ int drv_track(int w, int h, int stride, const unsigned char *img0, const unsigne
   coarse_wh[0] = c.cols; coarse_wh[1] = c.rows;
   for (int r = 0; r < c.rows; ++r)
     for (int q = 0; q < c.cols; ++q) coarse1[r * c.cols + q] = c.at<float>(r, q);
+  free(fl);
+  free(tc);
+  return 0;
+}
+
+// The frame loop of System::Track as the reference runs it (System.h:30-56, System.cpp:367-373,
+// 501-518), on frames in PAGEABLE host memory: PyramidBuffer::next() joins the preload thread and
+// rotates the three pyramids, computePyramid of frame t+2 starts on a fresh std::thread, and
+// KLTTrackFeatures(t -> t+1) runs meanwhile on the calling thread.  The list is re-seeded from
+// (x0, y0) every `reseed_every` frames (0 = never).  All of it is C++: this is what bench.py's
+// shim_drop_in block times.  out: [0] seconds for `steps` frames (after `warmup`), [1] tracked
+// features in those frames, [2] p50 and [3] p99 of the per-frame time in ms.
+int drv_track_stream(int w, int h, int nframes, const unsigned char *frames, int win, int levels, int border,
+                     int n, const float *x0, const float *y0, int reseed_every, int warmup, int steps,
+                     const double *invK, double *out, float *x, float *y, int *val) {
+  if (nframes < 2 || n < 1 || steps < 1) return -1;
+  KLT_TrackingContext tc = make_tc(win, levels, border);
+  KLT_FeatureList fl = KLTCreateFeatureList(tc, n);
+  std::vector<unsigned char *> frame(nframes);  // every frame in its own malloc'd (pageable) block
+  for (int k = 0; k < nframes; ++k) {
+    frame[k] = static_cast<unsigned char *>(malloc((size_t)w * h));
+    memcpy(frame[k], frames + (size_t)k * w * h, (size_t)w * h);
+  }
+  auto mat = [&](int k) { return cv::Mat(h, w, CV_8UC1, frame[k % nframes], w); };
+  Eigen::Matrix3d K;
+  for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) K(r, c) = invK[3 * r + c];
+  static std::vector<cv::Mat> pyr[3];
+  std::vector<cv::Mat> *ptrs[3] = {&pyr[0], &pyr[1], &pyr[2]};
+  cv::Mat cur = mat(0), nxt = mat(1);
+  computePyramid(tc, cur, *ptrs[1]);                                            // System.cpp:367-368
+  // GKLT_DRV_BREAKDOWN=1: mean time of the three parts of a frame on stderr
+  const bool breakdown = getenv("GKLT_DRV_BREAKDOWN") != nullptr;
+  double t_pyr = 0, t_join = 0, t_trk = 0;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto msec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  auto build = [&](const cv::Mat &img, std::vector<cv::Mat> &dst) {  // body of the preload thread
+    const auto a = now();
+    computePyramid(tc, img, dst);
+    t_pyr += msec(a, now());
+  };
+  std::thread preload(build, std::ref(nxt), std::ref(*ptrs[2]));                 // :370-373
+  std::vector<double> ms;
+  ms.reserve(steps);
+  double tracked = 0;
+  std::chrono::steady_clock::time_point t_begin;
+  for (int t = 0; t < warmup + steps; ++t) {
+    if (t == warmup) t_begin = std::chrono::steady_clock::now();
+    const auto q0 = std::chrono::steady_clock::now();
+    preload.join();                                                              // PyramidBuffer::next()
+    t_join += msec(q0, now());
+    std::vector<cv::Mat> *tmp = ptrs[0];
+    ptrs[0] = ptrs[1]; ptrs[1] = ptrs[2]; ptrs[2] = tmp;
+    nxt = mat(t + 2);
+    preload = std::thread(build, std::ref(nxt), std::ref(*ptrs[2]));             // :508-511
+    if (reseed_every > 0 ? t % reseed_every == 0 : t == 0)
+      for (int i = 0; i < n; ++i) { fl->feature[i]->x = x0[i]; fl->feature[i]->y = y0[i]; fl->feature[i]->val = 0; }
+    const auto q1 = now();
+    KLTTrackFeatures(tc, *ptrs[0], *ptrs[1], fl, K);                             // :515-518
+    t_trk += msec(q1, now());
+    if (t >= warmup) {
+      for (int i = 0; i < n; ++i) tracked += fl->feature[i]->val == KLT_TRACKED;
+      ms.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - q0).count());
+    }
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+  preload.join();
+  if (breakdown)
+    fprintf(stderr, "drv_track_stream: per frame computePyramid %.3f ms (preload thread), wait for it %.3f ms, "
+            "KLTTrackFeatures %.3f ms\n", t_pyr / (warmup + steps + 1), t_join / (warmup + steps), t_trk / (warmup + steps));
+  std::sort(ms.begin(), ms.end());
+  out[0] = secs; out[1] = tracked; out[2] = ms[ms.size() / 2]; out[3] = ms[std::min(ms.size() - 1, ms.size() * 99 / 100)];
+  for (int i = 0; i < n; ++i) { x[i] = fl->feature[i]->x; y[i] = fl->feature[i]->y; val[i] = fl->feature[i]->val; }
+  for (auto p : frame) free(p);
   free(fl);
   free(tc);
   return 0;

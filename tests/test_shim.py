@@ -168,3 +168,40 @@ def test_shim_smooth_and_gradients_match_oracle(drv, ok):
     rgx, rgy = ok.gradients(img, 1.0)
     for a, b in ((sm, ok.smooth(img, 1.0)), (gx, rgx), (gy, rgy)):
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("win,L,border,reseed", [(7, 3, -1, 4), (21, 2, 50, 0)])
+def test_shim_frame_loop_matches_oracle(drv, ok, win, L, border, reseed):
+    """drv_track_stream = the loop of System::Track (System.cpp:501-518) over the shim: pyramid of
+    frame t+2 on a preload std::thread WHILE KLTTrackFeatures(t -> t+1) runs on the calling thread,
+    three rotating pyramids, pageable frames.  The list after `steps` frames and the number of
+    tracked features must be those of the same chain on the oracle.  (win 21 / 2 levels / border 50
+    are the as-shipped parameters)"""
+    from gslam_amd import synth
+
+    H, W, n, nframes, warm, steps = 270, 480, 300, 5, 2, 7
+    frames = synth.make_stream(H, W, nframes, seed=21)
+    op = ok.make_params(window=win, levels=L, border=None if border < 0 else border)
+    x0, y0 = synth.lattice_seeds(H, W, n, op.borderx)
+    invK = np.linalg.inv(np.array([[400.0, 0, W / 2], [0, 400.0, H / 2], [0, 0, 1]]))
+    stack = np.ascontiguousarray(np.stack(frames))
+    out = np.zeros(4)
+    gx, gy, gv = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    dp = C.POINTER(C.c_double)
+    rc = drv.drv_track_stream(W, H, nframes, stack.ctypes.data_as(C.POINTER(C.c_uint8)), win, L, border, n,
+                              _fp(x0), _fp(y0), reseed, warm, steps, invK.ctypes.data_as(dp),
+                              out.ctypes.data_as(dp), _fp(gx), _fp(gy), _ip(gv))
+    assert rc == 0
+    pyr = [ok.compute_pyramid(op, f) for f in frames]
+    x = y = v = None
+    tracked = 0
+    for t in range(warm + steps):
+        if (t % reseed == 0) if reseed > 0 else t == 0:
+            x, y, v = x0.copy(), y0.copy(), np.zeros(n, np.int32)
+        x, y, v = ok.track_features(op, pyr[t % nframes], pyr[(t + 1) % nframes], x, y, v)[:3]
+        if t >= warm:
+            tracked += int((v == 0).sum())
+    assert (gv == v).all() and (gx == x).all() and (gy == y).all()
+    assert out[1] == tracked and tracked > 0.5 * n * steps
+    assert out[0] > 0 and out[2] > 0 and out[3] >= out[2]
