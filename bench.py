@@ -76,6 +76,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive legs")
     ap.add_argument("--no-shim", action="store_true", help="skip the shim_drop_in block")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="--gpus N launcher: seconds after which ranks still running are killed")
+    ap.add_argument("--launch-grace", type=float, default=10.0,
+                    help="--gpus N launcher: seconds the other ranks get after one rank has failed")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # tests: this rank exits 3 at once
     ap.add_argument("--select-variant", default="uniform", choices=["uniform", "plain", "round2"],
                     help="--config C5: selector flavour run every frame")
     ap.add_argument("--dry-launch", action="store_true",
@@ -105,7 +110,28 @@ def launch_ranks(a, argv):
                    LOCAL_WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE, text=True))
+    # A rank that dies before the first barrier leaves the others waiting in it for ever: when one
+    # rank has failed the rest get a short grace period, and the whole job has a deadline; what is
+    # still running then is killed (these exact children, by handle).
     rc = 0
+    deadline = time.monotonic() + a.launch_timeout
+    failed_at = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.monotonic()
+        if failed_at is None and any(c not in (None, 0) for c in codes):
+            failed_at = now
+        if now > deadline or (failed_at is not None and now > failed_at + a.launch_grace):
+            for r, p in enumerate(procs):
+                if p.poll() is None:
+                    print("bench.py: killing rank %d (%s)" % (
+                        r, "deadline of %.0f s passed" % a.launch_timeout if now > deadline else "another rank failed"),
+                        file=sys.stderr)
+                    p.kill()
+            break
+        time.sleep(0.05)
     outs = []
     for r, p in enumerate(procs):
         out, _ = p.communicate()
@@ -755,6 +781,10 @@ def main(argv=None):
     if a.dry_launch:
         print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "device": device,
                           "streams": shard_streams(a.streams, world, rank) if a.streams else None}), flush=True)
+        if a.fail_rank >= 0:  # launcher test: one rank dies, the others wait as if in a barrier
+            if rank == a.fail_rank:
+                return 3
+            time.sleep(600)
         return 0
     klt.lib()  # libgklt.so and the system HIP runtime, before torch can be imported
 

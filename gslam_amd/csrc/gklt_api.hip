@@ -925,6 +925,13 @@ extern "C" int gklt_copy_to_device(gklt_ctx *ctx, void *dst, const void *src, si
   GKLT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
   return 0;
 }
+extern "C" int gklt_device_mem_info(gklt_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+  if (!ctx || !free_bytes || !total_bytes) return GKLT_EINVAL;
+  if (int rc = use_device(ctx)) return rc;
+  GKLT_HIP(hipMemGetInfo(free_bytes, total_bytes));
+  return 0;
+}
+
 extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
   if (!ctx) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;

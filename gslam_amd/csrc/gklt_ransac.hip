@@ -308,22 +308,29 @@ int ransac_get(gklt_ctx *ctx, int n, int H, RansacScratch **out) {
   }
   if (!r) {
     r = new RansacScratch();
+    const size_t N = (size_t)std::max(n, 4096), HH = (size_t)std::max(H, 1000);
+    const int rc = [&]() -> int {
+      GKLT_HIP(hipMalloc(&r->d_key, sizeof(double) * 3 * N));
+      GKLT_HIP(hipMalloc(&r->d_cur, sizeof(double) * 3 * N));
+      GKLT_HIP(hipMalloc(&r->d_val, sizeof(int) * N));
+      GKLT_HIP(hipMalloc(&r->d_valid, N));
+      GKLT_HIP(hipMalloc(&r->d_pts, sizeof(double) * 8 * N));
+      GKLT_HIP(hipMalloc(&r->d_index, sizeof(int) * N));
+      GKLT_HIP(hipMalloc(&r->d_mats, sizeof(double) * 27));
+      GKLT_HIP(hipMalloc(&r->d_info, sizeof(int) * 4));
+      GKLT_HIP(hipMalloc(&r->d_F, sizeof(double) * 27 * HH));
+      GKLT_HIP(hipMalloc(&r->d_nmodels, sizeof(int) * HH));
+      GKLT_HIP(hipMalloc(&r->d_counts, sizeof(int) * 3 * HH));
+      GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->h_pinned), sizeof(int) * (4 + 4 * HH), hipHostMallocDefault));
+      return 0;
+    }();
+    if (rc) {  // a scratch is published only when every buffer exists
+      ransac_free(r);
+      return rc;
+    }
+    r->cap_n = (int)N;
+    r->cap_h = (int)HH;
     ctx->ransac = r;
-    r->cap_n = std::max(n, 4096);
-    r->cap_h = std::max(H, 1000);
-    const size_t N = (size_t)r->cap_n, HH = (size_t)r->cap_h;
-    GKLT_HIP(hipMalloc(&r->d_key, sizeof(double) * 3 * N));
-    GKLT_HIP(hipMalloc(&r->d_cur, sizeof(double) * 3 * N));
-    GKLT_HIP(hipMalloc(&r->d_val, sizeof(int) * N));
-    GKLT_HIP(hipMalloc(&r->d_valid, N));
-    GKLT_HIP(hipMalloc(&r->d_pts, sizeof(double) * 8 * N));
-    GKLT_HIP(hipMalloc(&r->d_index, sizeof(int) * N));
-    GKLT_HIP(hipMalloc(&r->d_mats, sizeof(double) * 27));
-    GKLT_HIP(hipMalloc(&r->d_info, sizeof(int) * 4));
-    GKLT_HIP(hipMalloc(&r->d_F, sizeof(double) * 27 * HH));
-    GKLT_HIP(hipMalloc(&r->d_nmodels, sizeof(int) * HH));
-    GKLT_HIP(hipMalloc(&r->d_counts, sizeof(int) * 3 * HH));
-    GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&r->h_pinned), sizeof(int) * (4 + 4 * HH), hipHostMallocDefault));
   }
   *out = r;
   return 0;

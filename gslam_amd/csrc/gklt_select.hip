@@ -644,7 +644,10 @@ __global__ __launch_bounds__(MT) void k_mis32_round(unsigned *__restrict__ state
       if constexpr (UNI) {
         const int x = x0 - r + tx, y = y0 - r + ty;  // inside the image: sval != 0
         const int c = (min(y / ug.gh, ug.ch - 1) - cy0) * ncx + min(x / ug.gw, ug.cw - 1) - cx0;
-        if (sval >> kU32ScoreBits) intmax = 1;  // does not fit: the host repeats the phase
+        // does not fit: the host repeats the phase on 64-bit keys.  (2^26 - 1 fits, but in the
+        // tile's last-ranked cell -- field 31 -- its key would be 0xFFFFFFFE, and two of them in a
+        // window combine to the 'accepted' marker 0xFFFFFFFF.)
+        if (sval >= (1u << kU32ScoreBits) - 1) intmax = 1;
         k = ((unsigned)cell_field[c] << kU32ScoreBits | (sval & ((1u << kU32ScoreBits) - 1))) << 1;
       } else {
         intmax |= sval == 0x7FFFFFFFu;
@@ -1293,22 +1296,29 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   }
   if (!s) {
     s = new SelScratch();
-    ctx->sel = s;
     s->cap_px = px;
     s->cap_sum = sum;
     s->cap_tiles = tiles;
     s->cap_slots = std::max(nslots, 4096);
-    for (auto &p : s->sum) GKLT_HIP(hipMalloc(&p, sizeof(float) * sum));
-    GKLT_HIP(hipMalloc(&s->state, sizeof(unsigned) * px));
-    GKLT_HIP(hipMalloc(&s->blocked, px));
-    GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * px));
-    GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * px));
-    GKLT_HIP(hipMalloc(&s->tile_left, sizeof(unsigned) * tiles));
-    GKLT_HIP(hipMalloc(&s->tile_changed, 2 * tiles));
-    GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
-    GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
-    GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
-    GKLT_HIP(hipHostMalloc(&s->h_counters, sizeof(unsigned) * (kMaxRounds + 1 + kPollExtra), hipHostMallocDefault));
+    const int rc = [&]() -> int {
+      for (auto &p : s->sum) GKLT_HIP(hipMalloc(&p, sizeof(float) * sum));
+      GKLT_HIP(hipMalloc(&s->state, sizeof(unsigned) * px));
+      GKLT_HIP(hipMalloc(&s->blocked, px));
+      GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * px));
+      GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * px));
+      GKLT_HIP(hipMalloc(&s->tile_left, sizeof(unsigned) * tiles));
+      GKLT_HIP(hipMalloc(&s->tile_changed, 2 * tiles));
+      GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
+      GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
+      GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
+      GKLT_HIP(hipHostMalloc(&s->h_counters, sizeof(unsigned) * (kMaxRounds + 1 + kPollExtra), hipHostMallocDefault));
+      return 0;
+    }();
+    if (rc) {  // a scratch is published only when every buffer exists
+      sel_free(s);
+      return rc;
+    }
+    ctx->sel = s;
   }
   if (s->w != w || s->h != h) s->last_rounds[0] = s->last_rounds[1] = 0;  // round hint of another image size
   s->w = w;
@@ -1649,18 +1659,25 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
   }
   if (!u) {
     u = new UniScratch();
-    sc->uni = u;
     u->ncell = ncell; u->w = sc->w; u->h = sc->h;
     const size_t px = (size_t)sc->w * sc->h;
-    GKLT_HIP(hipMalloc(&u->state0, sizeof(unsigned) * px));
-    GKLT_HIP(hipMalloc(&u->pos, sizeof(unsigned) * (size_t)sc->cap_list));
-    GKLT_HIP(hipMalloc(&u->rank, sizeof(unsigned) * (size_t)sc->cap_list));
-    GKLT_HIP(hipMalloc(&u->flags, 4 * sizeof(unsigned)));  // tail flags [0..1], need64 [2]
-    GKLT_HIP(hipMalloc(&u->cellmax, sizeof(unsigned long long) * ncell));
-    GKLT_HIP(hipMalloc(&u->tinfo, 4 * sizeof(unsigned long long)));
-    GKLT_HIP(hipMalloc(&u->cellcount, sizeof(int) * ncell));
-    GKLT_HIP(hipMalloc(&u->cellrank, sizeof(unsigned short) * ncell));
-    GKLT_HIP(hipHostMalloc(&u->h_cellcount, sizeof(int) * ncell, hipHostMallocDefault));
+    const int rc = [&]() -> int {
+      GKLT_HIP(hipMalloc(&u->state0, sizeof(unsigned) * px));
+      GKLT_HIP(hipMalloc(&u->pos, sizeof(unsigned) * (size_t)sc->cap_list));
+      GKLT_HIP(hipMalloc(&u->rank, sizeof(unsigned) * (size_t)sc->cap_list));
+      GKLT_HIP(hipMalloc(&u->flags, 4 * sizeof(unsigned)));  // tail flags [0..1], need64 [2]
+      GKLT_HIP(hipMalloc(&u->cellmax, sizeof(unsigned long long) * ncell));
+      GKLT_HIP(hipMalloc(&u->tinfo, 4 * sizeof(unsigned long long)));
+      GKLT_HIP(hipMalloc(&u->cellcount, sizeof(int) * ncell));
+      GKLT_HIP(hipMalloc(&u->cellrank, sizeof(unsigned short) * ncell));
+      GKLT_HIP(hipHostMalloc(&u->h_cellcount, sizeof(int) * ncell, hipHostMallocDefault));
+      return 0;
+    }();
+    if (rc) {
+      uni_free(u);
+      return rc;
+    }
+    sc->uni = u;
   }
   *out = u;
   return 0;

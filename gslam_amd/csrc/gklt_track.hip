@@ -1031,6 +1031,13 @@ WaveGeom wave_geom_compute(const gklt_ctx *ctx, int ww, int wh) {
   }
   g.epl = g.run ? g.run : (g.NA + 63) / 64;
   g.fpl = (g.NF + 63) / 64;
+  // the row-run kernels are instantiated for footprints of up to 13 texels per lane: a wider
+  // footprint (GKLT_TRACK_HALO 4 with a 19..21-px window) takes the element-per-lane mapping
+  if (g.run && g.fpl > 13) {
+    g.run = 0;
+    g.fstride = ww + 1 + 2 * g.halo;
+    g.epl = (g.NA + 63) / 64;
+  }
   g.lds = sizeof(float) * (size_t)(5 * prod_stride(g.NA) + 40) + (g.stage ? sizeof(float4) * (size_t)(g.fstride * (wh + 1 + 2 * g.halo) + 8) : 0);
   g.fits = g.epl <= 16 && g.fpl <= 16 && g.lds <= 48 * 1024;
   // the lane mappings divide by the window and footprint widths with a 16-bit reciprocal

@@ -227,6 +227,12 @@ class Context:
     def device_synchronize(self):
         _check(lib().gklt_device_synchronize(self.h))
 
+    def device_mem_info(self):
+        """(free, total) bytes of the context's GPU."""
+        f, t = C.c_size_t(), C.c_size_t()
+        _check(lib().gklt_device_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     # standalone P1 / P2 (convolve.h:12-13)
     def computeSmoothedImage(self, img, sigma):
         img = np.ascontiguousarray(img, np.float32)

@@ -163,8 +163,10 @@ int gklt_track_flist(gklt_ctx *ctx, gklt_pyramid *pyr1, gklt_pyramid *pyr2, gklt
 int gklt_flist_stats(gklt_ctx *ctx, gklt_flist *fl, uint64_t *tracked, uint64_t *iterations,
                      int reset);
 
-/* No counterpart in the reference.  For callers that cannot allocate device memory (code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): gklt_track() on host
+/* No counterpart in the reference.  For callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc, code that runs between the capture regions of a HIP
+ * graph).  Allocation-free but SYNCHRONOUS -- it waits on its stream and copies pageable arrays --
+ * so it cannot itself run while that stream is being captured.  gklt_track() on host
  * or device x / y / val arrays of n <= GKLT_NOALLOC_MAX_FEATURES entries, with the list staging and
  * the tracker counters in a fixed array that libgklt.so holds on every GPU it runs on (388 KiB,
  * until the process ends) instead of hipMalloc'd buffers; the call makes no hipMalloc / hipFree
@@ -425,6 +427,8 @@ int gklt_host_malloc_pinned(gklt_ctx *ctx, size_t bytes, void **out);
 int gklt_host_free_pinned(gklt_ctx *ctx, void *ptr);
 int gklt_copy_to_device(gklt_ctx *ctx, void *dst, const void *src, size_t bytes);
 int gklt_device_synchronize(gklt_ctx *ctx);
+/* hipMemGetInfo of the context's GPU (tests: the allocation-free entry point allocates nothing). */
+int gklt_device_mem_info(gklt_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 
 /* ---- measurement ---- */
 

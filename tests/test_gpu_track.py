@@ -82,6 +82,49 @@ def test_track_alternative_kernels_agree(klt, ok, gpu_ctx, window, levels, impl)
     _assert_same(got, ref)
 
 
+_HALO_SCRIPT = """
+import sys, numpy as np
+sys.path.insert(0, %(root)r)
+from gslam_amd import klt, synth
+from oracle import oracle as ok
+ok.build()
+H, W, n = 200, 320, 200
+T = synth.base_texture(H, W, seed=5)
+f = [synth.render_frame(T, H, W, k, seed=5) for k in range(2)]
+ctx = klt.Context(0)
+bad = 0
+for ww in (15, 19, 21):
+    gp, op = klt.make_params(window=ww, levels=2), ok.make_params(window=ww, levels=2)
+    ctx.set_params(gp)
+    x, y = synth.lattice_seeds(H, W, n, op.borderx)
+    val = np.zeros(n, np.int32)
+    p0, p1 = klt.Pyramid(ctx, W, H), klt.Pyramid(ctx, W, H)
+    p0.build(f[0]); p1.build(f[1])
+    got = klt.KLTTrackFeatures(ctx, p0, p1, x, y, val)
+    ref = ok.track_features(op, p0.planes(), p1.planes(), x, y, val)
+    bad += int((got[2] != ref[2]).sum() + (got[0] != ref[0]).sum() + (got[1] != ref[1]).sum())
+    assert (ref[2] == 0).sum() > n // 2
+    p0.close(); p1.close()
+ctx.close()
+print("MISMATCHES", bad)
+"""
+
+
+@pytest.mark.parametrize("halo", [2, 4])
+def test_track_footprint_halo_knob(klt, halo):
+    """GKLT_TRACK_HALO (read once per process, hence a child process) widens the LDS footprint of the
+    staged windows.  With halo 4 a 19..21-px window needs 15 texels per lane, more than the row-run
+    kernels are instantiated for: it must fall back to the element-per-lane mapping (ADVICE round 2:
+    it read uninitialised LDS), and every setting must give the oracle's bits."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GKLT_TRACK_HALO=str(halo))
+    r = subprocess.run([sys.executable, "-c", _HALO_SCRIPT % {"root": root}], env=env, capture_output=True,
+                       text=True, timeout=110)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "MISMATCHES 0" in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("ww,wh", [(15, 15), (17, 17), (19, 19), (21, 15), (15, 21), (19, 13), (17, 21), (23, 21), (21, 23)])
 def test_track_row_run_mapping_windows(klt, ok, gpu_ctx, ww, wh):
     """Staged windows 15..21 px wide take the row-run mapping (a lane owns 7 consecutive elements of

@@ -76,3 +76,17 @@ def test_bench_rejects_gpus_that_disagree_with_world_size():
     # bad arguments fail in the launcher, before any rank starts
     r = _bench("--gpus", "2", "--dry-launch", "--config", "nope")
     assert r.returncode != 0
+
+
+def test_bench_launcher_does_not_hang_when_a_rank_dies():
+    """A rank that exits before the first barrier leaves the others waiting: the launcher kills them
+    after the grace period and reports failure; a job that outlives --launch-timeout is killed too."""
+    import time
+    t0 = time.monotonic()
+    r = _bench("--gpus", "3", "--dry-launch", "--fail-rank", "1", "--launch-grace", "1")
+    assert r.returncode != 0 and time.monotonic() - t0 < 60
+    assert "rank 1 exited with code 3" in r.stderr and "killing rank 0 (another rank failed)" in r.stderr
+    t0 = time.monotonic()
+    r = _bench("--gpus", "2", "--dry-launch", "--fail-rank", "7", "--launch-timeout", "2")   # nobody fails, all wait
+    assert r.returncode != 0 and time.monotonic() - t0 < 60
+    assert "deadline of 2 s passed" in r.stderr

@@ -72,3 +72,30 @@ def test_track_noalloc_limits(klt, gpu_ctx):
         assert t == 0 and (v < 0).all()
     finally:
         p0.close()
+
+
+def test_track_noalloc_allocates_no_device_memory(klt, gpu_ctx):
+    """The property itself: free device memory (hipMemGetInfo) is the same before and after the calls,
+    including the FIRST call on a fresh context."""
+    H, W, n = 135, 240, 700
+    T = synth.base_texture(H, W, seed=3)
+    f = [synth.render_frame(T, H, W, k, seed=3) for k in range(2)]
+    gp = klt.make_params(window=7, levels=3)
+    ctx = klt.Context(0, gp)                     # fresh: nothing but its two streams and invK block
+    p0, p1 = klt.Pyramid(ctx, W, H), klt.Pyramid(ctx, W, H)
+    try:
+        p0.build(f[0]); p1.build(f[1])
+        ctx.device_synchronize()
+        x, y = synth.lattice_seeds(H, W, n, gp.borderx)
+        val = np.zeros(n, np.int32)
+        free0, _ = ctx.device_mem_info()
+        first = klt.track_noalloc(ctx, p0, p1, x, y, val)
+        free1, _ = ctx.device_mem_info()
+        for _ in range(20):
+            again = klt.track_noalloc(ctx, p0, p1, x, y, val)
+        free2, _ = ctx.device_mem_info()
+        assert free1 == free0 and free2 == free0, (free0, free1, free2)
+        _same(again, first)
+        _same(first, klt.KLTTrackFeatures(ctx, p0, p1, x, y, val))
+    finally:
+        p0.close(); p1.close(); ctx.close()
