@@ -595,6 +595,17 @@ def shim_drop_in(frames, steps=256, warmup=16):
     return res
 
 
+def cpu_model():
+    """CPU model name of the box the cpu_baseline leg ran on (core count AND model)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def c5_params(cfg):
     sel = cfg["select"]
     kw = dict(window=cfg["window"], levels=cfg["levels"], min_eigenvalue=sel["min_eigenvalue"],
@@ -752,6 +763,7 @@ def main_c5(a, ctx, cfg, dist, rank, world):
         v, cdt, ncpu = cpu_baseline_c5(cfg, frames, a.cpu_frames or 4, threads, variant,
                                        0.0 if a.cpu_frames else CPU_SAMPLE_SECONDS)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads, "kind": "port",
+                               "cpu_model": cpu_model(),
                                "sample": "%d frames of the same stream (pyramid + integral images + selection + "
                                          "track), oracle/ C restatement with OpenMP, %.1f s wall" % (ncpu, cdt)}
     for p in ring:
@@ -998,7 +1010,7 @@ def main(argv=None):
         v, cdt, nf = cpu_baseline(params_kw, frames, seeds, a.cpu_frames or 8, threads, secs)
         v1, cdt1, nf1 = cpu_baseline(params_kw, frames, seeds, max((a.cpu_frames or 8) // 16, 2), 1, secs / 2)
         out["cpu_baseline"] = {"value": v, "unit": "tracked_features*frames/s", "cores": threads,
-                               "kind": "port",
+                               "kind": "port", "cpu_model": cpu_model(),
                                "one_core": {"value": v1, "sample": "%d frames, %.1f s wall" % (nf1, cdt1)},
                                "sample": "%d frames of the same stream (pyramid + track), oracle/ C "
                                          "restatement with OpenMP, %.1f s wall" % (nf, cdt)}

@@ -166,6 +166,10 @@ extern "C" int gklt_feature_list_capacity(int nFeatures) {  // KLTUtil.cpp:53-55
 }
 
 extern "C" int gklt_count_remaining(int n, const int *val) {  // LK.hpp:27-38
+  if (n > 0 && !val) {  // (found by the UBSAN run of tests/test_sanitize.py)
+    set_error("gklt_count_remaining: %d entries but no array", n);
+    return GKLT_EINVAL;
+  }
   int c = 0;
   for (int i = 0; i < n; ++i) c += val[i] >= 0;
   return c;

@@ -40,7 +40,7 @@ for it in range(N):
     gw = int(rng.integers(max(8, mindist), 70)); gh = int(rng.integers(max(8, mindist), 70))
     grid = (min(gw, W), min(gh, H))
     cap = max(100 * n, 8192)
-    impl, iters = int(rng.choice([0, 1])), int(rng.choice([1, 2, 3, 5]))
+    impl, iters = int(rng.choice([0, 0, 1, 2])), int(rng.choice([1, 2, 3, 5, 12]))
     ctx.set_select_impl(impl); ctx.set_select_iters(iters)
     replace = rng.random() < 0.35
     try:
