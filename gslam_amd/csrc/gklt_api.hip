@@ -166,12 +166,15 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
     GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
     // this device's copy of the allocation-free entry point's scratch array
     GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
+    GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_chain_err), sizeof(unsigned), hipHostMallocDefault));
+    *c->h_chain_err = 0;
     return 0;
   }();
   if (rc) {  // release what the failed set-up had created (gklt_last_error keeps its message)
     if (c->s_pyr) (void)hipStreamDestroy(c->s_pyr);
     if (c->s_trk) (void)hipStreamDestroy(c->s_trk);
     if (c->d_invk) (void)hipFree(c->d_invk);
+    if (c->h_chain_err) (void)hipHostFree(c->h_chain_err);
     delete c;
     return rc;
   }
@@ -193,6 +196,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   stage_free(&ctx->stage_plane);
   stage_free(&ctx->stage_trk);
   (void)hipFree(ctx->d_trk);
+  if (ctx->h_chain_err) (void)hipHostFree(ctx->h_chain_err);
   (void)hipFree(ctx->d_frame);
   (void)hipFree(ctx->d_invk);
   (void)hipFree(ctx->d_norm);
@@ -230,6 +234,12 @@ extern "C" int gklt_sync(gklt_ctx *ctx) {
   if (int rc = use_device(ctx)) return rc;
   GKLT_HIP(hipStreamSynchronize(ctx->s_pyr));
   GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
+  if (*ctx->h_chain_err) {
+    *ctx->h_chain_err = 0;
+    set_error("a coarse-level tile gave up waiting for the level above (k_level_chain): the pyramids "
+              "built since the last gklt_sync are incomplete");
+    return GKLT_EHIP;
+  }
   return 0;
 }
 
@@ -266,6 +276,17 @@ extern "C" int gklt_pyramid_create(gklt_ctx *ctx, int width, int height, gklt_py
     gklt_pyramid_destroy(py);
     return GKLT_ENOMEM;
   }
+  {  // one flag per 64 x 32 tile of levels 1 .. L-1 (k_level_chain)
+    int tiles = 0;
+    for (int l = 1; l < py->nlevels; ++l) tiles += ((py->lv[l].w + 63) / 64) * ((py->lv[l].h + 31) / 32);
+    py->chain_tiles = tiles;
+    if (tiles > 0 && (hipMalloc(&py->chain_flags, sizeof(unsigned) * tiles) != hipSuccess ||
+                      hipMemset(py->chain_flags, 0, sizeof(unsigned) * tiles) != hipSuccess)) {
+      set_error("hipMalloc of the pyramid's tile flags failed");
+      gklt_pyramid_destroy(py);
+      return GKLT_ENOMEM;
+    }
+  }
   if (hipEventCreateWithFlags(&py->ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&py->consumed, hipEventDisableTiming) != hipSuccess) {
     set_error("hipEventCreate for a pyramid failed");
@@ -286,6 +307,7 @@ extern "C" int gklt_pyramid_destroy(gklt_pyramid *py) {
     if (py->lv[l].tex) (void)hipFree(py->lv[l].tex);
   }
   if (py->tmp) (void)hipFree(py->tmp);
+  if (py->chain_flags) (void)hipFree(py->chain_flags);
   if (py->ready) (void)hipEventDestroy(py->ready);
   if (py->consumed) (void)hipEventDestroy(py->consumed);
   delete py;
@@ -456,7 +478,13 @@ int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const 
       if (int rc = enqueue_build_unfused(ctx, s, py[i], src[i], src_stride, t)) return rc;
     return 0;
   }
+  // single frame, default kernels, every level an exact 2x decimation: levels 1 .. L-1 in one launch
+  bool chain = n == 1 && ctx->chain_levels && p0->nlevels >= 3 && (ctx->pyr_impl == 0 || ctx->pyr_impl == 2) &&
+               p0->chain_flags;
+  for (int l = 0; chain && l + 1 < p0->nlevels; ++l)
+    chain = p0->lv[l].w == 2 * p0->lv[l + 1].w && p0->lv[l].h == 2 * p0->lv[l + 1].h;
   for (int l = 0; l < p0->nlevels; ++l) {
+    if (chain && l == 1) return launch_level_chain(ctx, s, py[0], t.pyr, t.gradg, t.gradd);
     const Level &a = p0->lv[l];
     const bool last = l + 1 == p0->nlevels;
     const bool exact = !last && a.w == 2 * p0->lv[l + 1].w && a.h == 2 * p0->lv[l + 1].h;
@@ -959,6 +987,12 @@ extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
 // 0 = one fused launch per level when the radii allow it (default); 1 = separate kernels; 3 = the
 // streaming form of the fused kernel; 4 = the fused kernel with mul+add contracted into FMAs (NOT
 // bit-identical: inside north_star's 1e-4 relative tolerance; never the default)
+extern "C" int gklt_ctx_set_chain(gklt_ctx *ctx, int on) {
+  if (!ctx) return GKLT_EINVAL;
+  ctx->chain_levels = on ? 1 : 0;
+  return 0;
+}
+
 extern "C" int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 4) return GKLT_EINVAL;
   ctx->pyr_impl = impl;

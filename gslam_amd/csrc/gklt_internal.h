@@ -89,6 +89,8 @@ struct gklt_ctx {
   int stage_frame_next = 0;
   gklt::HostStage stage_plane;     // plane downloads (s_pyr's thread)
   gklt::HostStage stage_trk;       // gklt_track's list, invK and bearing vectors (s_trk's thread)
+  unsigned *h_chain_err = nullptr;  // page-locked word a k_level_chain tile raises when it gives up waiting
+  int chain_levels = 1;             // gklt_ctx_set_chain: 1 = coarse levels of a single-frame build in one launch
   void *d_trk = nullptr;           // device image of stage_trk
   size_t d_trk_bytes = 0;
   gklt_flist *scratch_list = nullptr;
@@ -126,6 +128,11 @@ struct gklt_pyramid {
   hipEvent_t consumed = nullptr;  // recorded on s_trk after a tracker launch that read it
   bool has_ready = false, has_consumed = false;
   bool built_on_pyr = false;  // last written by gklt_pyramid_build / _upload, i.e. on s_pyr
+  // k_level_chain (levels 1 .. L-1 in one launch): one flag per tile of those levels, holding the
+  // epoch of the last launch that finished the tile
+  unsigned *chain_flags = nullptr;
+  int chain_tiles = 0;
+  unsigned chain_epoch = 0;
 };
 
 struct gklt_flist {
@@ -178,6 +185,9 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
 int launch_level_fma(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src,
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out);
+// levels 1 .. L-1 of one pyramid in one launch (exact 2x decimations only)
+int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const Taps &pyr, const Taps &g,
+                       const Taps &d);
 // streaming form of the fused level kernel (gklt_pyramid_stream.hip)
 bool level_streamable(int w, int h, int level, const Taps &s0);
 int launch_level_stream(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src, int n,

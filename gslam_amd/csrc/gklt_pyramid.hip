@@ -566,13 +566,14 @@ struct LevelIO {
   float *down[GKLT_MAX_LOOKAHEAD];
 };
 
-template <typename SrcT, int R0, int RP, int RG, bool DOWN, int LNT>
-__global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, int h, Taps s0,
-                                              Taps pyr, Taps g, Taps d,
-                                              float *__restrict__ img_out, int w2, int h2) {
-  const SrcT *__restrict__ src = static_cast<const SrcT *>(io.src[blockIdx.z]);
-  Texel *__restrict__ tex = io.tex[blockIdx.z];
-  float *__restrict__ down = io.down[blockIdx.z];
+// one 64 x 32 tile of one level (origin x0, y0): the body of k_level and of k_level_chain
+// THROUGH: the decimated image is stored write-through at agent scope (k_level_chain: tiles of the
+// same launch on other XCDs read it)
+template <typename SrcT, int R0, int RP, int RG, bool DOWN, int LNT, bool THROUGH = false>
+__device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *__restrict__ tex,
+                                           float *__restrict__ down, int stride, int w, int h,
+                                           const Taps &s0, const Taps &pyr, const Taps &g, const Taps &d,
+                                           float *__restrict__ img_out, int w2, int h2, int x0, int y0) {
   constexpr int HI = DOWN ? (RP > RG ? RP : RG) : RG;
   using G = LevelGeom<R0, HI, LNT>;
   constexpr int RPW = LTH / (LNT / 64);  // output rows per wave
@@ -581,7 +582,6 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
   extern __shared__ __align__(16) float lds[];
   float *I = lds;                        // IHh x AW
   float *scratch = I + G::IHh * G::AW;   // level-0 phase: S, A; afterwards: rowd, rowg, rowp
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * LTH;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   if constexpr (R0 > 0) {
@@ -700,8 +700,95 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
       const float b = __shfl_xor(a, 1), e = __shfl_xor(c, 1);
       const float m = GKLT_MEAN2X2(a, b, c, e);
       const int y = y0 / 2 + RPW / 2 * wave + jj;
-      if (!(lane & 1) && x < w2 && y < h2) down[(size_t)y * w2 + x] = m;
+      if (!(lane & 1) && x < w2 && y < h2) {
+        if constexpr (THROUGH)
+          __hip_atomic_store(reinterpret_cast<unsigned *>(down + (size_t)y * w2 + x), __float_as_uint(m),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          down[(size_t)y * w2 + x] = m;
+      }
     }
+  }
+}
+
+template <typename SrcT, int R0, int RP, int RG, bool DOWN, int LNT>
+__global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, int h, Taps s0,
+                                              Taps pyr, Taps g, Taps d,
+                                              float *__restrict__ img_out, int w2, int h2) {
+  level_tile<SrcT, R0, RP, RG, DOWN, LNT>(static_cast<const SrcT *>(io.src[blockIdx.z]), io.tex[blockIdx.z],
+                                          io.down[blockIdx.z], stride, w, h, s0, pyr, g, d, img_out, w2, h2,
+                                          blockIdx.x * TW, blockIdx.y * LTH);
+}
+
+// ---- levels 1 .. L-1 of one pyramid in ONE launch.
+// A frame-at-a-time build is a chain of dependent launches (level l+1 reads the image level l
+// wrote), and at 1080p the three coarse levels are 5-6 us each, mostly launch latency and tail.
+// Here every tile of every coarse level is a workgroup of one launch, ordered level by level; a
+// tile of level l >= 2 waits until the (at most 4 x 4) tiles of level l-1 that produce its haloed
+// input have published their part of the decimated image:
+//   producer: write-through (agent-scope) stores of the decimated image -> wait for them ->
+//             workgroup barrier -> one lane stores the launch's epoch into the tile's flag.  (A
+//             plain store + agent-scope release fence is the textbook form, but that fence writes
+//             back the whole L2 -- with level 0's texels in it -- in every wavefront: the
+//             frame-at-a-time step went from 44 to 106 us with it);
+//   consumer: up to 16 lanes poll one flag each (agent-scope loads) -> barrier -> agent-scope
+//             acquire fence (invalidates this XCD's stale lines of the image) -> staging loads.
+// Workgroups are dispatched in index order and a tile only waits for tiles of lower index, which
+// wait for nothing later than themselves: every wait ends.  The wait is bounded all the same: a
+// tile that gives up raises *err (reported by the next synchronising call) instead of hanging.
+struct ChainArgs {
+  int nlev;                          // levels in the launch (pyramid levels 1 .. nlev)
+  int first_tile[GKLT_MAX_LEVELS];   // per launch level: first workgroup, tiles per row, size
+  int tiles_x[GKLT_MAX_LEVELS], tiles_y[GKLT_MAX_LEVELS], w[GKLT_MAX_LEVELS], h[GKLT_MAX_LEVELS];
+  const float *img[GKLT_MAX_LEVELS];
+  Texel *tex[GKLT_MAX_LEVELS];
+  float *down[GKLT_MAX_LEVELS];      // nullptr for the last level
+  unsigned *flags;                   // one word per tile of the launch
+  unsigned epoch;
+  unsigned *err;
+};
+
+template <int RP, int RG, int LNT>
+__global__ __launch_bounds__(LNT) void k_level_chain(ChainArgs a, Taps pyr, Taps g, Taps d) {
+  int li = 0;
+  for (int i = 1; i < a.nlev; ++i)
+    if ((int)blockIdx.x >= a.first_tile[i]) li = i;
+  const int tile = blockIdx.x - a.first_tile[li];
+  const int tx = tile % a.tiles_x[li], ty = tile / a.tiles_x[li];
+  const int x0 = tx * TW, y0 = ty * LTH, w = a.w[li], h = a.h[li];
+  if (li > 0) {
+    // producers: tiles of the level above whose 32 x 16 outputs meet this tile's haloed input
+    // (columns x0 - 8 .. x0 + 71, rows y0 - 5 .. y0 + 36, reflected into the image: inside it)
+    constexpr int HIP = (((RP > RG ? RP : RG) + 3) / 4) * 4, HI = RP > RG ? RP : RG;
+    const int px0 = max(x0 - HIP, 0) / (TW / 2), px1 = min(min(x0 + TW + HIP, w) - 1, w - 1) / (TW / 2);
+    const int py0 = max(y0 - HI, 0) / (LTH / 2), py1 = min(min(y0 + LTH + HI, h) - 1, h - 1) / (LTH / 2);
+    const int npx = px1 - px0 + 1, np = npx * (py1 - py0 + 1);
+    if ((int)threadIdx.x < np) {
+      const int pxx = min(px0 + (int)threadIdx.x % npx, a.tiles_x[li - 1] - 1);
+      const int pyy = min(py0 + (int)threadIdx.x / npx, a.tiles_y[li - 1] - 1);
+      const unsigned *flag = a.flags + a.first_tile[li - 1] + pyy * a.tiles_x[li - 1] + pxx;
+      int spins = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+        if (++spins > (1 << 20)) {  // ~ a second: something is badly wrong; do not hang the GPU
+          *a.err = 1u;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  if (a.down[li])
+    level_tile<float, 0, RP, RG, true, LNT, true>(a.img[li], a.tex[li], a.down[li], w, w, h, g, pyr, g, d, nullptr,
+                                            a.w[li + 1 < a.nlev ? li + 1 : li], a.h[li + 1 < a.nlev ? li + 1 : li], x0, y0);
+  else
+    level_tile<float, 0, RP, RG, false, LNT>(a.img[li], a.tex[li], nullptr, w, w, h, g, g, g, d, nullptr, 0, 0, x0, y0);
+  if (a.down[li]) {
+    __builtin_amdgcn_s_waitcnt(0);  // this wavefront's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+      __hip_atomic_store(a.flags + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -934,6 +1021,37 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
 }
 
 #ifndef GKLT_PYR_FMA
+// Levels 1 .. L-1 of one pyramid in one launch (k_level_chain); the caller has checked that every
+// level is an exact 2x decimation of the one above and that the radii are the fused kernels'.
+int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const Taps &pyr, const Taps &g,
+                       const Taps &d) {
+  ChainArgs a{};
+  a.nlev = py->nlevels - 1;
+  if (a.nlev < 1 || !py->chain_flags) return GKLT_EINVAL;
+  int tiles = 0;
+  for (int i = 0; i < a.nlev; ++i) {
+    const Level &L = py->lv[i + 1];
+    a.first_tile[i] = tiles;
+    a.tiles_x[i] = (L.w + TW - 1) / TW;
+    a.tiles_y[i] = (L.h + LTH - 1) / LTH;
+    a.w[i] = L.w;
+    a.h[i] = L.h;
+    a.img[i] = L.img;
+    a.tex[i] = L.tex;
+    a.down[i] = i + 1 < a.nlev ? py->lv[i + 2].img : nullptr;
+    tiles += a.tiles_x[i] * a.tiles_y[i];
+  }
+  if (tiles > py->chain_tiles) return GKLT_EINVAL;
+  a.flags = py->chain_flags;
+  a.epoch = ++py->chain_epoch;
+  a.err = ctx->h_chain_err;
+  constexpr size_t lds = level_lds<0, 5, 3, true>();
+  ProfScope ps(ctx, s, GKLT_K_LEVELN);
+  hipLaunchKernelGGL((k_level_chain<5, 3, 512>), dim3(tiles), dim3(512), lds, s, a, pyr, g, d);
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_smooth_u8(gklt_ctx *ctx, hipStream_t s, const uint8_t *src, int stride, int w, int h,
                      const Taps &g, float *dst) {
   return launch_smooth_any<uint8_t, 0>(ctx, s, GKLT_K_SMOOTH0, src, stride, w, h, g, dst, 0, 0);

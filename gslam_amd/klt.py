@@ -177,6 +177,9 @@ class Context:
         """wavefronts per tracker launch (0 = default cap of 4096)"""
         _check(lib().gklt_ctx_set_track_waves(self.h, int(waves)))
 
+    def set_chain(self, on):
+        _check(lib().gklt_ctx_set_chain(self.h, int(on)))
+
     def set_pyramid_impl(self, impl):
         """0 = fused level kernels when the radii allow (default), 1 = separate kernels."""
         _check(lib().gklt_ctx_set_pyramid_impl(self.h, int(impl)))

@@ -453,11 +453,18 @@ int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
  * agree with it to 1e-4 relative (the tolerance this path is specified to), positions and status
  * flags of a few features per thousand differ in the last digits.  Never the default. */
 int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
-/* Plain / ...2 selector rounds: 0 = 32-bit keys in LDS (default), 1 = the 64-bit-key rounds the
- * Uniform selector uses.  Identical results. */
+/* A/B switch (default 1): a single-frame build runs levels 1 .. L-1 in ONE launch whose tiles wait
+ * for the tiles of the level above through per-tile flags, instead of one launch per level.  Same
+ * results. */
+int gklt_ctx_set_chain(gklt_ctx *ctx, int on);
+/* Suppression rounds of the selectors (plain / ...2, and the uncapped phase of the Uniform one):
+ * 0 (default) = rounds on box tops -- one candidate per (r+1) x (r+1) box is examined instead of
+ * every pixel -- for radii 4..~45, dense rounds on 32-bit keys otherwise; 1 = dense rounds on
+ * 64-bit keys; 2 = dense rounds on 32-bit keys.  Identical results. */
 int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl);
-/* Selector: fixpoint iterations a tile runs in LDS per suppression launch (1..64, default 3;
- * 1 = one iteration per launch).  Results do not depend on it. */
+/* Selector: fixpoint iterations a tile runs in LDS per suppression launch (1..64; default 3 for the
+ * dense rounds, 12 for the rounds on box tops; 1 = one iteration per launch).  Results do not
+ * depend on it. */
 int gklt_ctx_set_select_iters(gklt_ctx *ctx, int iters);
 /* Suppression launches the last selection on this context needed until no candidate was left
  * undecided: rounds[0] = plain / ...2 selector or phase A (no per-cell caps) of the Uniform

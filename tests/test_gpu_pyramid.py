@@ -255,3 +255,46 @@ def test_contracted_level_kernels_end_to_end_c2(klt, ok, gpu_ctx):
     both = same_status & (rv == 0)
     d = np.maximum(np.abs(gx[both] - rx[both]), np.abs(gy[both] - ry[both]))
     assert (d <= 0.01).mean() >= 0.999, "positions: %.5f within 0.01 px, max %g" % ((d <= 0.01).mean(), d.max())
+
+
+@pytest.mark.parametrize("H,W,win,L", [
+    (1080, 1920, 7, 4),    # C2: 255 + 72 + 20 tiles in the chained launch
+    (2160, 3840, 11, 5),   # C3: 1020 + 255 + 72 + 20 tiles, more than the chip holds at once
+    (256, 384, 7, 3),      # two coarse levels, few tiles
+    (160, 96, 21, 5),      # coarsest levels smaller than one tile (10 x 6 pixels at level 4)
+    (432, 776, 7, 4),      # 432 -> 216 -> 108 -> 54, 776 -> 388 -> 194 -> 97: exact halvings, ragged tiles
+])
+def test_chained_coarse_levels(klt, ok, H, W, win, L):
+    """A single-frame build runs levels 1 .. L-1 in ONE launch (k_level_chain: a tile waits for the
+    tiles of the level above through per-tile flags).  The planes are the oracle's bits and those of
+    the launch-per-level build, also when the same pyramid is rebuilt again and again (the flags
+    carry the epoch of the launch that set them) and when two pyramids alternate."""
+    T = synth.base_texture(H, W, seed=23)
+    frames = [synth.render_frame(T, H, W, k, seed=23) for k in range(3)]
+    gp = klt.make_params(window=win, levels=L)
+    ctx = klt.Context(0, gp)
+    pa, pb = klt.Pyramid(ctx, W, H), klt.Pyramid(ctx, W, H)
+    try:
+        ok.set_threads(8)
+        refs = [ok.compute_pyramid(ok.make_params(window=win, levels=L), f) for f in frames]
+        ok.set_threads(1)
+        for rep in range(3):                       # rebuild the same pyramids: epochs 1, 2, 3, ...
+            for k, f in enumerate(frames):
+                py = (pa, pb)[k % 2]
+                py.build(f)
+                got = py.planes()
+                for i, (a, b) in enumerate(zip(got, refs[k])):
+                    assert (a.view(np.uint32) == b.view(np.uint32)).all(), (rep, k, i)
+        ctx.set_chain(0)                           # one launch per level: the same planes
+        pa.build(frames[0])
+        for i, (a, b) in enumerate(zip(pa.planes(), refs[0])):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), ("per level", i)
+        ctx.set_chain(1)
+        # many builds queued back to back without a host synchronisation in between
+        for k in range(12):
+            (pa, pb)[k % 2].build(frames[k % 3])
+        ctx.sync()
+        for i, (a, b) in enumerate(zip(pb.planes(), refs[11 % 3])):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), ("queued", i)
+    finally:
+        pa.close(); pb.close(); ctx.close()
