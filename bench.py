@@ -76,6 +76,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive legs")
     ap.add_argument("--no-shim", action="store_true", help="skip the shim_drop_in block")
+    ap.add_argument("--no-select-prepare", action="store_true",
+                    help="C5: compute the integral images inside the selection (no gklt_select_prepare)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="--gpus N launcher: seconds after which ranks still running are killed")
     ap.add_argument("--launch-grace", type=float, default=10.0,
@@ -662,6 +664,8 @@ def main_c5(a, ctx, cfg, dist, rank, world):
             cur, nxt = ring[t % 3], ring[(t + 1) % 3]
             ptr, stride, _ = store.frame(t + 1)
             nxt.build_from_device(ptr, stride)
+            if not a.no_select_prepare:   # integral images of frame t+1 behind its build, beside select(t)
+                klt.select_prepare(ctx, nxt)
             klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, variant, fl, grid=sel["grid"])
             klt.track_flist(ctx, cur, nxt, fl)
         state["t"] += k
@@ -736,7 +740,7 @@ def main_c5(a, ctx, cfg, dist, rank, world):
         "config": {"workload": "C5: re-detection every frame on the synthetic %dx%d u8 stream: "
                                "gklt_select_from_pyramid (SELECT_ALL, %s, gridSize %dx%d px, min_eigenvalue %d, "
                                "mindist %d, %d features) on the current pyramid, then gklt_track_flist to the "
-                               "next frame (%d-level pyramid, %dx%d window), pyramid(t+1) built meanwhile; "
+                               "next frame (%d-level pyramid, %dx%d window), pyramid(t+1) and its integral images built meanwhile; "
                                "frames resident in HBM, one frame per call, 1 stream per GPU" % (
                                    W, H, a.select_variant, sel["grid"][0], sel["grid"][1], sel["min_eigenvalue"],
                                    sel["mindist"], n, cfg["levels"], cfg["window"], cfg["window"]),

@@ -467,6 +467,7 @@ int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const 
   const gklt_pyramid *p0 = py[0];
   BuildTaps t;
   if (int rc = build_taps(ctx->prm, p0->nlevels, &t)) return rc;
+  for (int i = 0; i < n; ++i) py[i]->build_gen = ++ctx->build_counter;
 
   // One fused launch per level (for the whole batch) when the radii are the instantiated ones
   // (the reference's defaults); level l+1 must be an exact 2x decimation for the fused
@@ -572,6 +573,7 @@ extern "C" int gklt_pyramid_upload(gklt_ctx *ctx, gklt_pyramid *py, int level, i
   GKLT_HIP(hipMemcpy2DAsync(stage, sizeof(float) * L.w, src, sizeof(float) * src_stride,
                             sizeof(float) * L.w, L.h, hipMemcpyHostToDevice, s));
   if (int rc = launch_tex_insert(ctx, s, L.tex, L.w * L.h, plane, stage)) return rc;
+  py->build_gen = ++ctx->build_counter;
   GKLT_HIP(hipEventRecord(py->ready, s));
   py->has_ready = true;
   GKLT_HIP(hipStreamSynchronize(s));

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <mutex>
 #include <string>
@@ -89,6 +90,7 @@ struct gklt_ctx {
   int stage_frame_next = 0;
   gklt::HostStage stage_plane;     // plane downloads (s_pyr's thread)
   gklt::HostStage stage_trk;       // gklt_track's list, invK and bearing vectors (s_trk's thread)
+  std::atomic<unsigned long long> build_counter{0};  // source of gklt_pyramid::build_gen (unique per context)
   unsigned *h_chain_err = nullptr;  // page-locked word a k_level_chain tile raises when it gives up waiting
   int chain_levels = 1;             // gklt_ctx_set_chain: 1 = coarse levels of a single-frame build in one launch
   void *d_trk = nullptr;           // device image of stage_trk
@@ -130,6 +132,8 @@ struct gklt_pyramid {
   bool built_on_pyr = false;  // last written by gklt_pyramid_build / _upload, i.e. on s_pyr
   // k_level_chain (levels 1 .. L-1 in one launch): one flag per tile of those levels, holding the
   // epoch of the last launch that finished the tile
+  unsigned long long build_gen = 0;  // a value no other build on the context has, set by every build /
+                                     // plane upload (gklt_select_prepare's tag)
   unsigned *chain_flags = nullptr;
   int chain_tiles = 0;
   unsigned chain_epoch = 0;

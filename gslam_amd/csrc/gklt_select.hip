@@ -1244,6 +1244,14 @@ struct SelScratch {
   int w = 0, h = 0, cap_list = 0, cap_slots = 0;
   size_t cap_px = 0, cap_sum = 0, cap_tiles = 0;  // allocated sizes: the scratch of a large image serves smaller ones
   float *sum[3] = {nullptr, nullptr, nullptr};  // (h+1) x (w+1)
+  // gklt_select_prepare: integral images computed ahead of the selection, on the build stream, into
+  // one of two further sets; tagged with the pyramid and its build generation
+  float *pre[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  const gklt_pyramid *pre_py[2] = {nullptr, nullptr};
+  unsigned long long pre_gen[2] = {0, 0};
+  hipEvent_t pre_done[2] = {nullptr, nullptr};
+  int pre_next = 0;
+  float *const *active = nullptr;  // the set the selection in progress reads (sum or pre[k])
   unsigned *state = nullptr;
   unsigned char *blocked = nullptr;
   unsigned long long *list = nullptr;
@@ -1269,6 +1277,10 @@ constexpr int kPollExtra = 4, kPollNeed64 = kMaxRounds + 1, kPollCount = kMaxRou
 void sel_free(SelScratch *s) {
   if (!s) return;
   for (auto *p : s->sum) (void)hipFree(p);
+  for (auto &set : s->pre)
+    for (auto *p : set) (void)hipFree(p);
+  for (auto e : s->pre_done)
+    if (e) (void)hipEventDestroy(e);
   (void)hipFree(s->state);
   (void)hipFree(s->blocked);
   (void)hipFree(s->list);
@@ -1323,6 +1335,7 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   if (s->w != w || s->h != h) s->last_rounds[0] = s->last_rounds[1] = 0;  // round hint of another image size
   s->w = w;
   s->h = h;
+  s->active = s->sum;
   s->cap_list = (int)px;  // mindist 1 accepts every candidate
   s->ntiles = s->cap_tiles;  // the two halves of tile_changed lie cap_tiles apart
   s->tile_bytes = sizeof(unsigned) * s->cap_tiles;
@@ -1331,17 +1344,32 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
 }
 
 int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *py,
-                                  SelScratch *sc, int level = 0) {
+                                  SelScratch *sc, int level = 0, float *const *dst = nullptr) {
   const int w = py->lv[level].w, h = py->lv[level].h;
+  if (!dst) dst = sc->sum;
   {
     ProfScope ps(ctx, s, GKLT_K_INTEGRAL);
     hipLaunchKernelGGL(k_integral_rows, dim3((h + kIR - 1) / kIR), dim3(256), 0, s, py->lv[level].tex, w, h,
-                       sc->sum[0], sc->sum[1], sc->sum[2]);
-    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(256), 0, s, sc->sum[0],
-                       sc->sum[1], sc->sum[2], w, h);
+                       dst[0], dst[1], dst[2]);
+    hipLaunchKernelGGL(k_integral_cols, dim3((w + 1 + 63) / 64, 3), dim3(256), 0, s, dst[0], dst[1], dst[2],
+                       w, h);
   }
   GKLT_HIP(hipGetLastError());
   return 0;
+}
+
+// Integral images of level 0 for the selection on `py`: the set gklt_select_prepare computed ahead
+// (the tracker stream then only waits for it), else computed now on stream s.
+static int select_sums_for(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *py, SelScratch *sc) {
+  for (int k = 0; k < 2; ++k)
+    if (sc->pre_py[k] == py && sc->pre_gen[k] == py->build_gen && sc->pre[k][0]) {
+      GKLT_HIP(hipStreamWaitEvent(s, sc->pre_done[k], 0));
+      sc->active = sc->pre[k];
+      sc->pre_py[k] = nullptr;  // consumed: the set is free again once this selection has returned
+      return 0;
+    }
+  sc->active = sc->sum;
+  return select_integrals_from_pyramid(ctx, s, py, sc);
 }
 
 // S1-S4 on device-resident sums and a device-resident list (x, y, val of n features).
@@ -1371,8 +1399,8 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   }
   {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    hipLaunchKernelGGL(k_score, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->sum[0], sc->sum[1],
-                       sc->sum[2], overwrite ? (const unsigned char *)nullptr : sc->blocked, w, h,
+    hipLaunchKernelGGL(k_score, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->active[0], sc->active[1],
+                       sc->active[2], overwrite ? (const unsigned char *)nullptr : sc->blocked, w, h,
                        hw, hh, bx, by, step, P.min_eigenvalue, round2, 0x7fffffff, sc->state);
   }
   hipLaunchKernelGGL(k_lost_slots, dim3(1), dim3(1024), 0, s, fval, n, overwrite, sc->slots,
@@ -1818,7 +1846,7 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   // costs no copy of the map
   auto score_into = [&](unsigned *dst) {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->sum[0], sc->sum[1], sc->sum[2],
+    hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->active[0], sc->active[1], sc->active[2],
                        (const unsigned char *)nullptr, w, h, hw, hh, bx, by, step,
                        P.min_eigenvalue, 0, 0x7ffffffe, dst);
   };
@@ -2064,7 +2092,7 @@ extern "C" int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *py, int mod
     if (int rc = sel_get(ctx, py->lv[0].w, py->lv[0].h, fl->n, &sc)) return rc;
     hipStream_t s = ctx->s_trk;
     GKLT_HIP(hipStreamWaitEvent(s, py->ready, 0));
-    if (int rc = select_integrals_from_pyramid(ctx, s, py, sc)) return rc;
+    if (int rc = select_sums_for(ctx, s, py, sc)) return rc;
     int n_out = fl->n;
     if (int rc = select_uniform_on_device(ctx, s, sc, gridW, gridH, fl->n, fl->capacity, fl->x,
                                           fl->y, fl->val, &n_out))
@@ -2083,12 +2111,39 @@ extern "C" int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *py, int mod
   if (int rc = sel_get(ctx, py->lv[0].w, py->lv[0].h, fl->n, &sc)) return rc;
   hipStream_t s = ctx->s_trk;
   GKLT_HIP(hipStreamWaitEvent(s, py->ready, 0));
-  if (int rc = select_integrals_from_pyramid(ctx, s, py, sc)) return rc;
+  if (int rc = select_sums_for(ctx, s, py, sc)) return rc;
   // replacing with nothing lost is a no-op (:442-447): k_lost_slots yields 0 slots and the
   // fixpoint result is simply not written anywhere, so no host round trip is needed for it
   if (int rc = select_on_device(ctx, s, sc, mode, round2, fl->n, fl->x, fl->y, fl->val)) return rc;
   GKLT_HIP(hipEventRecord(py->consumed, s));
   py->has_consumed = true;
+  return 0;
+}
+
+extern "C" int gklt_select_prepare(gklt_ctx *ctx, gklt_pyramid *py) {
+  if (!ctx || !py || py->ctx != ctx) return GKLT_EINVAL;
+  GKLT_HIP(hipSetDevice(ctx->device));
+  if (!py->has_ready || !py->built_on_pyr) {
+    set_error("gklt_select_prepare needs a pyramid built by gklt_pyramid_build");
+    return GKLT_EINVAL;
+  }
+  const int w = py->lv[0].w, h = py->lv[0].h;
+  SelScratch *sc;
+  if (int rc = sel_get(ctx, w, h, 0, &sc)) return rc;
+  const int k = sc->pre_next;
+  sc->pre_next ^= 1;
+  if (!sc->pre[k][0]) {
+    for (auto &p : sc->pre[k]) GKLT_HIP(hipMalloc(&p, sizeof(float) * sc->cap_sum));
+    GKLT_HIP(hipEventCreateWithFlags(&sc->pre_done[k], hipEventDisableTiming));
+  }
+  // on the build stream, behind the build: runs beside whatever the tracker stream is doing (the
+  // integral kernels are chains of dependent adds that occupy a fraction of the chip)
+  hipStream_t s = ctx->s_pyr;
+  sc->pre_py[k] = nullptr;
+  if (int rc = select_integrals_from_pyramid(ctx, s, py, sc, 0, sc->pre[k])) return rc;
+  GKLT_HIP(hipEventRecord(sc->pre_done[k], s));
+  sc->pre_py[k] = py;
+  sc->pre_gen[k] = py->build_gen;
   return 0;
 }
 

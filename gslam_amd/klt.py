@@ -665,6 +665,10 @@ def select_from_pyramid(ctx, pyr, mode, variant, fl, grid=(20, 20)):
     _check(lib().gklt_select_from_pyramid(ctx.h, pyr.h, mode, variant, fl.h, grid[0], grid[1]))
 
 
+def select_prepare(ctx, pyr):
+    _check(lib().gklt_select_prepare(ctx.h, pyr.h))
+
+
 def seed_from_level(ctx, pyr, level, fl, nFeatures):
     """gklt_seed_from_level: keyframe seeds (System.cpp:407-420) selected on pyramid level `level`."""
     _check(lib().gklt_seed_from_level(ctx.h, pyr.h, int(level), fl.h, int(nFeatures)))

@@ -201,6 +201,13 @@ int gklt_select(gklt_ctx *ctx, int mode, int variant, const float *sumDxx, const
                 float *y, int *val, int gridW, int gridH);
 /* Same selection with the integral images computed on the device from pyramid level 0 and the
  * list resident on the device; asynchronous apart from the convergence polls. */
+/* gklt_select_prepare (optional, no counterpart in the reference: System.cpp:385-392 computes the
+ * integral images right before selecting): computes the integral images of `pyr` (built by
+ * gklt_pyramid_build) AHEAD, on the build stream right behind the build, so that a later
+ * gklt_select_from_pyramid on the same, unchanged pyramid finds them ready -- in a loop
+ * build(t+1); prepare(t+1); select(t); track(t -> t+1) they are computed while select(t) runs.
+ * Same bits either way; at most two preparations are kept. */
+int gklt_select_prepare(gklt_ctx *ctx, gklt_pyramid *pyr);
 int gklt_select_from_pyramid(gklt_ctx *ctx, gklt_pyramid *pyr, int mode, int variant,
                              gklt_flist *fl, int gridW, int gridH);
 

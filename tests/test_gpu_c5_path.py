@@ -32,8 +32,11 @@ def _params(klt, ok, bordery):
     return gp, op
 
 
-def _run_stream(klt, ok, ctx, fl, frames, n_list, what, rounds_seen):
-    """C5 loop over `frames` with the list at `n_list` entries; returns the list length afterwards."""
+def _run_stream(klt, ok, ctx, fl, frames, n_list, what, rounds_seen, prepare=False):
+    """C5 loop over `frames` with the list at `n_list` entries; returns the list length afterwards.
+    prepare: the integral images of frame t+1 are computed ahead (gklt_select_prepare), on the build
+    stream, while the selection on frame t runs -- as bench.py does; the first selection finds
+    nothing prepared and computes its own."""
     H, W = frames[0].shape
     gp, op = _params(klt, ok, H - GRID[1] * (H // GRID[1]))
     ctx.set_params(gp)
@@ -44,6 +47,8 @@ def _run_stream(klt, ok, ctx, fl, frames, n_list, what, rounds_seen):
         for t in range(len(frames) - 1):
             cur, nxt = ring[t % 3], ring[(t + 1) % 3]
             nxt.build(frames[t + 1])
+            if prepare:
+                klt.select_prepare(ctx, nxt)
             klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, klt.VARIANT_UNIFORM, fl, grid=GRID)
             rounds_seen.append(ctx.select_rounds())
             sel = fl.download()
@@ -66,14 +71,15 @@ def _run_stream(klt, ok, ctx, fl, frames, n_list, what, rounds_seen):
     return n_list
 
 
-def test_c5_bench_path_matches_oracle(klt, ok, gpu_ctx):
+@pytest.mark.parametrize("prepare", [False, True])
+def test_c5_bench_path_matches_oracle(klt, ok, gpu_ctx, prepare):
     n = 100
     fl = klt.FeatureList(gpu_ctx, 100 * n)
     rounds = []
     try:
         fl.upload(np.zeros(n, np.float32), np.zeros(n, np.float32), np.full(n, -1, np.int32))
         small = synth.make_stream(270, 480, 5, seed=synth.BASE_SEED + 5)
-        n1 = _run_stream(klt, ok, gpu_ctx, fl, small, n, "270x480", rounds)
+        n1 = _run_stream(klt, ok, gpu_ctx, fl, small, n, "270x480", rounds, prepare)
         assert n1 > n                                       # the first selection grew the list (:1257)
         # the slots ran out in the first selection: capped phase (phase B) after the uncapped one
         assert rounds[0][0] >= 1 and rounds[0][1] >= 1, rounds
@@ -82,12 +88,12 @@ def test_c5_bench_path_matches_oracle(klt, ok, gpu_ctx):
         # 270x480 grid must not be used (gklt_select.hip sel_get / uni ranks)
         big = synth.make_stream(1080, 1920, 2, seed=synth.BASE_SEED + 6)
         rounds_big = []
-        n2 = _run_stream(klt, ok, gpu_ctx, fl, big, n1, "1080p", rounds_big)
+        n2 = _run_stream(klt, ok, gpu_ctx, fl, big, n1, "1080p", rounds_big, prepare)
         assert n2 > n1
         # and back to the small size with the 1080p list length: every slot beyond the accepted
         # candidates is KLT_NOT_FOUND, the list does not shrink
         again = []
-        n3 = _run_stream(klt, ok, gpu_ctx, fl, small[:3], n2, "270x480 again", again)
+        n3 = _run_stream(klt, ok, gpu_ctx, fl, small[:3], n2, "270x480 again", again, prepare)
         assert n3 == n2
         assert all(r[0] >= 1 and r[1] == 0 for r in again), again   # slots never ran out: no phase B
     finally:
@@ -123,3 +129,34 @@ def test_c5_round_hint_too_small_or_too_large(klt, ok, gpu_ctx, hint):
         gpu_ctx.set_select_iters(3)
         pyr.close()
         fl.close()
+
+
+def test_select_prepare_is_tied_to_the_build(klt, ok, gpu_ctx):
+    """Prepared integral images are used only for the pyramid and the build they were computed from:
+    rebuilding the pyramid with another frame, or selecting on another pyramid, computes fresh ones."""
+    H, W, n = 135, 240, 60
+    f = synth.make_stream(H, W, 3, seed=synth.BASE_SEED + 11)
+    gp, op = _params(klt, ok, 8)
+    gpu_ctx.set_params(gp)
+    pa, pb = klt.Pyramid(gpu_ctx, W, H), klt.Pyramid(gpu_ctx, W, H)
+    fl = klt.FeatureList(gpu_ctx, 100 * n)
+    try:
+        def check(pyr, frame, what):
+            fl.upload(np.zeros(n, np.float32), np.zeros(n, np.float32), np.full(n, -1, np.int32))
+            klt.select_from_pyramid(gpu_ctx, pyr, klt.SELECT_ALL, klt.VARIANT_PLAIN, fl)
+            o = ok.compute_pyramid(op, frame)
+            ref = ok.select_features(op, ok.SELECT_ALL, ok.VARIANT_PLAIN, *ok.integral_products(o[1], o[2]), n)
+            _same(fl.download(), ref, what)
+        pa.build(f[0]); klt.select_prepare(gpu_ctx, pa)
+        check(pa, f[0], "prepared and used")
+        pa.build(f[0]); klt.select_prepare(gpu_ctx, pa)
+        pa.build(f[1])                                   # rebuilt after the preparation: stale
+        check(pa, f[1], "stale preparation ignored")
+        pb.build(f[2]); pa.build(f[0]); klt.select_prepare(gpu_ctx, pa)
+        check(pb, f[2], "another pyramid")
+        check(pa, f[0], "still there for its own pyramid")
+        klt.select_prepare(gpu_ctx, pa); klt.select_prepare(gpu_ctx, pb); klt.select_prepare(gpu_ctx, pa)
+        check(pb, f[2], "two preparations kept")
+        check(pa, f[0], "the newer one of the same pyramid")
+    finally:
+        fl.close(); pa.close(); pb.close()
