@@ -1,6 +1,7 @@
 // C ABI of libgklt.so: contexts, device-resident pyramids and feature lists, stream/event
 // ordering between pyramid builds and tracker launches, and per-kernel event timing.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "gklt_internal.h"
@@ -161,8 +162,19 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
   c->device = device;
   gklt_default_params(&c->prm);
   const int rc = [&]() -> int {
-    GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
-    GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+    // GKLT_CU_SPLIT=k (experiment, round 3): the build stream on the first k compute units of the
+    // mask, the tracker stream on the other 256 - k, instead of both streams on the whole chip
+    const char *split = std::getenv("GKLT_CU_SPLIT");
+    const int k = split ? std::atoi(split) : 0;
+    if (k > 0 && k < 256) {
+      uint32_t lo[8] = {0}, hi[8] = {0};
+      for (int b = 0; b < 256; ++b) (b < k ? lo : hi)[b / 32] |= 1u << (b % 32);
+      GKLT_HIP(hipExtStreamCreateWithCUMask(&c->s_pyr, 8, lo));
+      GKLT_HIP(hipExtStreamCreateWithCUMask(&c->s_trk, 8, hi));
+    } else {
+      GKLT_HIP(hipStreamCreateWithFlags(&c->s_pyr, hipStreamNonBlocking));
+      GKLT_HIP(hipStreamCreateWithFlags(&c->s_trk, hipStreamNonBlocking));
+    }
     GKLT_HIP(hipMalloc(&c->d_invk, 9 * sizeof(double)));
     // this device's copy of the allocation-free entry point's scratch array
     GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));

@@ -279,6 +279,22 @@ __device__ __forceinline__ float corr_win(const float (&v)[N], int c, const Taps
   return acc;
 }
 
+#ifdef GKLT_PYR_FMA
+// taps k[1 .. R + 1] of the polyphase pyramid filter (see level_tile), k[0] unused
+template <int R>
+struct PolyTaps {
+  float k[R + 2];
+};
+// sum_{k = 1 .. R + 1} h[k] * (v[c + k] + v[c + 1 - k]): the decimated pixel whose 2 x 2 block starts at c
+template <int R, int N>
+__device__ __forceinline__ float poly_win(const float (&v)[N], int c, const PolyTaps<R> &t) {
+  float acc = t.k[1] * (v[c + 1] + v[c]);
+#pragma unroll
+  for (int k = 2; k <= R + 1; ++k) acc = acc + t.k[k] * (v[c + k] + v[c + 1 - k]);
+  return acc;
+}
+#endif
+
 template <int R, typename SrcT>
 __device__ __forceinline__ void stage_fast(const SrcT *__restrict__ src, int stride, int w, int h,
                                            int x0, int y0, float *in) {
@@ -583,6 +599,17 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
   float *I = lds;                        // IHh x AW
   float *scratch = I + G::IHh * G::AW;   // level-0 phase: S, A; afterwards: rowd, rowg, rowp
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef GKLT_PYR_FMA
+  // The contracted build folds the 2 x 2 mean into the pyramid filter: the decimated pixel is
+  // sum_m h[m] I(2x' + m), m = -RP .. RP + 1, h[m] = (g[m] + g[m-1]) / 2 = h[1 - m] -- RP + 1 distinct
+  // taps, evaluated at the decimated sites only (a quarter of the sites, half of them per pass)
+  [[maybe_unused]] PolyTaps<RP> hp;
+  if constexpr (DOWN) {
+#pragma unroll
+    for (int k = 1; k <= RP; ++k) hp.k[k] = 0.5f * (pyr.k[k] + pyr.k[k - 1]);
+    hp.k[RP + 1] = 0.5f * pyr.k[RP];
+  }
+#endif
 
   if constexpr (R0 > 0) {
     float *S = scratch;               // SH x SW source window
@@ -642,12 +669,20 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
     load_groups<G::NGI>(I + ty * G::AW + 4 * gq, v);
     constexpr int C = G::OI + HI;
     if constexpr (DOWN) {
+#ifdef GKLT_PYR_FMA
+      // polyphase: the filter is evaluated at the two decimated columns of the group only
+      float2 op;
+      op.x = poly_win<RP>(v, C + 0, hp);
+      op.y = poly_win<RP>(v, C + 2, hp);
+      *reinterpret_cast<float2 *>(rowp + ty * (TW / 2) + 2 * gq) = op;
+#else
       float4 op;
       op.x = corr_win<RP, +1>(v, C + 0, pyr);
       op.y = corr_win<RP, +1>(v, C + 1, pyr);
       op.z = corr_win<RP, +1>(v, C + 2, pyr);
       op.w = corr_win<RP, +1>(v, C + 3, pyr);
       *reinterpret_cast<float4 *>(rowp + ty * TW + 4 * gq) = op;
+#endif
     }
     const int tg = ty - GOFF;
     if (tg >= 0 && tg < GH) {
@@ -687,6 +722,26 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
       }
     }
   }
+#ifdef GKLT_PYR_FMA
+  if constexpr (DOWN) {  // polyphase column pass at the decimated rows: lane = (row half, column)
+    constexpr int DPL = RPW / 4;  // decimated rows per lane: a wave owns RPW / 2 of them, 32 columns wide
+    static_assert(RPW % 4 == 0, "two lane halves share a wave's decimated rows");
+    const int xq = lane & 31, half = lane >> 5;
+    float v[2 * DPL + 2 * RP];
+    // decimated row j of this lane = tile row 2 * (RPW/2 * wave + DPL * half + j): taps at I rows
+    // r0 - RP .. r0 + RP + 1 with r0 = that tile row + HI
+    const int rbase = RPW * wave + 2 * DPL * half + HI - RP;
+#pragma unroll
+    for (int i = 0; i < 2 * DPL + 2 * RP; ++i) v[i] = rowp[(rbase + i) * (TW / 2) + xq];
+    const int x = x0 / 2 + xq;
+#pragma unroll
+    for (int j = 0; j < DPL; ++j) {
+      const float m = poly_win<RP>(v, RP + 2 * j, hp);
+      const int y = y0 / 2 + RPW / 2 * wave + DPL * half + j;
+      if (x < w2 && y < h2) down[(size_t)y * w2 + x] = m;
+    }
+  }
+#else
   if constexpr (DOWN) {  // pyramid column pass -> 2x2 mean -> next level
     float v[RPW + 2 * RP], o[RPW];
 #pragma unroll
@@ -709,6 +764,7 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
       }
     }
   }
+#endif
 }
 
 template <typename SrcT, int R0, int RP, int RG, bool DOWN, int LNT>

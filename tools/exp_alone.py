@@ -4,8 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gslam_amd import klt, synth
-cfg = dict(synth.CONFIGS["C2"]); H, W, n = cfg["H"], cfg["W"], cfg["n"]
-gp = klt.make_params(window=cfg["window"], levels=cfg["levels"])
+cfg = dict(synth.CONFIGS[os.environ.get("CFG", "C2")]); H, W, n = cfg["H"], cfg["W"], cfg["n"]
+gp = klt.make_params(window=cfg["window"], levels=cfg["levels"], border=cfg.get("border"))
 ctx = klt.Context(0, gp)
 NFR = int(os.environ.get("NFR", "16"))
 frames = synth.make_stream(H, W, NFR)
