@@ -452,6 +452,19 @@ struct U32Grid {
   unsigned *need64;
 };
 
+// start of a phase of rounds, one launch instead of up to four fills: every tile live and "changed",
+// optionally the round counters and the need64 flag cleared
+__global__ void k_rounds_reset(unsigned *__restrict__ tile_left, int ntile_words,
+                               unsigned *__restrict__ tile_changed_words, int nchanged_words,
+                               unsigned *__restrict__ counters, int ncounters,
+                               unsigned *__restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ntile_words) tile_left[i] = 0xFFFFFFFFu;
+  if (i < nchanged_words) tile_changed_words[i] = 0x01010101u;
+  if (i < ncounters) counters[i] = 0u;
+  if (i == 0 && flag) *flag = 0u;
+}
+
 // counters[round] = undecided candidates left after this round (summed over tiles)
 template <int R>
 __global__ __launch_bounds__(MT) void k_mis_round(unsigned *__restrict__ state, int w, int h,
@@ -1274,6 +1287,17 @@ constexpr int kRoundBatch = 24;  // rounds per host sync: a converged round cost
 // counters (every host synchronisation leaves the GPU idle for ~25-40 us)
 constexpr int kPollExtra = 4, kPollNeed64 = kMaxRounds + 1, kPollCount = kMaxRounds + 2;
 
+// every tile live and changed; with_counters: the per-round counters too; flag (optional) cleared
+static int rounds_reset(hipStream_t s, SelScratch *sc, bool with_counters, unsigned *flag) {
+  const int ntile = (int)sc->cap_tiles, nch = (int)((2 * sc->cap_tiles + 3) / 4);
+  const int ncnt = with_counters ? kMaxRounds + 1 : 0;
+  const int n = std::max(std::max(ntile, nch), std::max(ncnt, 1));
+  hipLaunchKernelGGL(k_rounds_reset, dim3((n + 255) / 256), dim3(256), 0, s, sc->tile_left, ntile,
+                     reinterpret_cast<unsigned *>(sc->tile_changed), nch, sc->counters, ncnt, flag);
+  GKLT_HIP(hipGetLastError());
+  return 0;
+}
+
 void sel_free(SelScratch *s) {
   if (!s) return;
   for (auto *p : s->sum) (void)hipFree(p);
@@ -1319,7 +1343,7 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
       GKLT_HIP(hipMalloc(&s->list, sizeof(unsigned long long) * px));
       GKLT_HIP(hipMalloc(&s->rank, sizeof(unsigned) * px));
       GKLT_HIP(hipMalloc(&s->tile_left, sizeof(unsigned) * tiles));
-      GKLT_HIP(hipMalloc(&s->tile_changed, 2 * tiles));
+      GKLT_HIP(hipMalloc(&s->tile_changed, 2 * tiles + 4));  // (cleared in whole words)
       GKLT_HIP(hipMalloc(&s->counters, sizeof(unsigned) * (kMaxRounds + 1)));
       GKLT_HIP(hipMalloc(&s->slots, sizeof(int) * (size_t)s->cap_slots));
       GKLT_HIP(hipMalloc(&s->nslots, sizeof(int)));
@@ -1390,7 +1414,7 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
     set_error("selector supports images up to 65535 px per side");
     return GKLT_EINVAL;
   }
-  GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
+  if (int rc = rounds_reset(s, sc, true, nullptr)) return rc;
   if (!overwrite) {
     GKLT_HIP(hipMemsetAsync(sc->blocked, 0, (size_t)w * h, s));
     if (n > 0)
@@ -1434,8 +1458,6 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   // up to r deep into the neighbouring tiles)
   const int gate = tops ? (tg.cw >= 2 * rr && tg.ch >= 2 * rr) : (rr <= MH);
   const int local_iters = tops ? ctx->sel_tops_iters : ctx->sel_local_iters;
-  GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));
-  GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
   int round = 1;
   bool done = false;
   while (!done) {
@@ -1718,9 +1740,10 @@ static int uni_get(SelScratch *sc, int ncell, UniScratch **out) {
 // converged instead of costing a host synchronisation of its own.  The poll also fetches the
 // need64 flag (h_counters[kPollNeed64]) and counters[0] (h_counters[kPollCount]).
 enum { kUniKeys64 = 0, kUniKeys32 = 1, kUniTops = 2 };  // round kernels of the uncapped phase
+// clear_counters: the phase starts a selection (or restarts one): round counters and need64 cleared
 static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *u, const UGrid &g,
-                      UCaps caps, int r, int *round_io, int keys = kUniKeys64,
-                      const std::function<int()> &tail = {}) {
+                      UCaps caps, int r, int *round_io, int keys, const std::function<int()> &tail,
+                      bool clear_counters) {
   const int w = sc->w, h = sc->h;
   const bool keys32 = keys == kUniKeys32, tops = keys == kUniTops;
   const size_t lds = tops ? tops_lds_bytes(r) : keys32 ? mis32_lds_bytes(r) : mis_lds_bytes(r);
@@ -1738,8 +1761,7 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
   const dim3 grid = tops ? dim3((w + tg.cw - 1) / tg.cw, (h + tg.ch - 1) / tg.ch)
                          : dim3((w + MW - 1) / MW, (h + MH - 1) / MH);
   const dim3 pgrid((w + 255) / 256, h);
-  GKLT_HIP(hipMemsetAsync(sc->tile_left, 0xFF, sc->tile_bytes, s));  // a phase starts: all tiles live
-  GKLT_HIP(hipMemsetAsync(sc->tile_changed, 1, 2 * sc->ntiles, s));
+  if (int rc = rounds_reset(s, sc, clear_counters, clear_counters ? u->flags + 2 : nullptr)) return rc;  // a phase starts: all tiles live
   // with caps a decision also depends on the cell's counters and maximum, which change without
   // any tile of the neighbourhood changing: no gating there
   // (and only where nothing beyond the 8 neighbouring tiles can change what a tile sees)
@@ -1775,13 +1797,20 @@ static int uni_rounds(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, UniScratch *
     GKLT_HIP(hipGetLastError());
     if (tail)
       if (int rc = tail()) return rc;
-    GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
-                            sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollNeed64, u->flags + 2, sizeof(unsigned),
-                            hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollCount, sc->counters, sizeof(unsigned),
-                            hipMemcpyDeviceToHost, s));
-    GKLT_HIP(hipStreamSynchronize(s));
+    if (tops) {  // one copy: counters[0] is the number of accepted candidates; no need64 with these keys
+      GKLT_HIP(hipMemcpyAsync(sc->h_counters, sc->counters, sizeof(unsigned) * round, hipMemcpyDeviceToHost, s));
+      GKLT_HIP(hipStreamSynchronize(s));
+      sc->h_counters[kPollCount] = sc->h_counters[0];
+      sc->h_counters[kPollNeed64] = 0;
+    } else {
+      GKLT_HIP(hipMemcpyAsync(sc->h_counters + first, sc->counters + first,
+                              sizeof(unsigned) * (round - first), hipMemcpyDeviceToHost, s));
+      GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollNeed64, u->flags + 2, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, s));
+      GKLT_HIP(hipMemcpyAsync(sc->h_counters + kPollCount, sc->counters, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, s));
+      GKLT_HIP(hipStreamSynchronize(s));
+    }
     for (int k = first; k < round && !done; ++k)
       if (sc->h_counters[k] == 0) {
         done = true;
@@ -1840,7 +1869,6 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   }
   const UGrid g{gridW, gridH, cw, ch, u->cellrank};
   const dim3 pgrid((w + 255) / 256, h);
-  GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
   // the candidates' scores; evaluated again (same bits) where a later step needs the initial map:
   // a selection whose slots never run out -- every frame of a video after the first few -- then
   // costs no copy of the map
@@ -1887,14 +1915,11 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     GKLT_HIP(hipGetLastError());
     return 0;
   };
-  GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
-  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys, enqueue_collect)) return rc;
+  if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, keys, enqueue_collect, true)) return rc;
   if (keys32 && sc->h_counters[kPollNeed64]) {
     score_into(sc->state);
-    GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
-    GKLT_HIP(hipMemsetAsync(u->flags + 2, 0, sizeof(unsigned), s));
     round = 1;
-    if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, kUniKeys64, enqueue_collect)) return rc;
+    if (int rc = uni_rounds(ctx, s, sc, u, g, nocaps, r, &round, kUniKeys64, enqueue_collect, true)) return rc;
   }
 
   unsigned nacc = sc->h_counters[kPollCount];
@@ -1919,9 +1944,8 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
     hipLaunchKernelGGL(k_u_reset, pgrid, dim3(256), 0, s, sc->state, u->state0, w, h, g, u->tinfo);
     GKLT_HIP(hipMemsetAsync(u->cellcount, 0, sizeof(int) * ncell, s));
     GKLT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(u->cellcount + cellT), a1, 1, s));
-    GKLT_HIP(hipMemsetAsync(sc->counters, 0, sizeof(unsigned) * (kMaxRounds + 1), s));
     round = 1;
-    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round, kUniKeys64, enqueue_collect)) return rc;  // phase B
+    if (int rc = uni_rounds(ctx, s, sc, u, g, caps, r, &round, kUniKeys64, enqueue_collect, true)) return rc;  // phase B
     nacc = sc->h_counters[kPollCount];
     if (int rc = enqueue_rank(nacc)) return rc;
     // is a grown slot left unfilled?  (see the comment at the top of this section)
