@@ -808,7 +808,18 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist  # after libgklt.so: see the module docstring
 
-        dist.init_process_group("gloo")
+        # gloo announces its connections on the C-level stdout ("[Gloo] Rank 0 is connected to ..."),
+        # which would precede rank 0's ONE JSON line: send whatever the rendezvous prints to stderr
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     cfg = dict(synth.CONFIGS[a.config])
     H, W, n = cfg["H"], cfg["W"], cfg["n"]
