@@ -597,6 +597,19 @@ def shim_drop_in(frames, steps=256, warmup=16):
     return res
 
 
+def like_for_like(config, pcie, shim):
+    """The host-resident figures of the line in one sentence (they lead `config.workload`)."""
+    parts = []
+    if shim and isinstance(shim.get(config), dict) and "value" in shim[config]:
+        parts.append("unchanged-GSLAM drop-in path through the shim (pageable frames) %.1f M feature*frames/s, "
+                     "%.3f ms/frame [shim_drop_in]" % (shim[config]["value"] / 1e6, shim[config]["ms_per_frame"]))
+    if pcie:
+        parts.append("library API with pinned host frames copied inside the timed region %.1f M frame at a time, "
+                     "%.1f M with lookahead [pcie_inclusive]" % (
+                         pcie["frame_at_a_time"]["value"] / 1e6, pcie.get("lookahead", pcie["frame_at_a_time"])["value"] / 1e6))
+    return "; ".join(parts) if parts else "not measured in this run (--main-only / --no-pcie / --no-shim / rank > 0)"
+
+
 def cpu_model():
     """CPU model name of the box the cpu_baseline leg ran on (core count AND model)."""
     try:
@@ -972,11 +985,12 @@ def main(argv=None):
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s: synthetic %dx%d u8 stream, %d features, %d-level pyramid, %dx%d window, "
-                               "1 independent stream per GPU; frames RESIDENT IN HBM before the timed "
-                               "region, handed over %s; the drop-in call pattern (one frame per call, "
-                               "preload depth 1) is `frame_at_a_time`, host-resident frames are "
-                               "`pcie_inclusive`" % (
+                               "1 independent stream per GPU.  LIKE-FOR-LIKE with the reference's frame loop "
+                               "(frames start in HOST memory, SURVEY 3.1): %s.  `value` = frames RESIDENT IN HBM "
+                               "before the timed region, handed over %s; the drop-in call pattern with "
+                               "HBM-resident frames is `frame_at_a_time`" % (
                                    a.config, W, H, n, cfg["levels"], cfg["window"], cfg["window"],
+                                   like_for_like(a.config, pcie, shim),
                                    ("%d frames per gklt_lookahead_submit call" % B) if B else
                                    "one frame per gklt_pipeline_step call"),
                    "frames_per_s": world * a.steps / dt_max,

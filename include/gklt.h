@@ -308,7 +308,10 @@ gklt_pyramid *gklt_pipeline_pyramid(gklt_pipeline *p, int which);
  * iteration count for confidence `prob` capped at max_iters (OpenCV: 1000), counter-based sampler
  * seeded by `seed`; all max_iters hypotheses are evaluated in parallel and the sequential
  * bookkeeping is replayed on the host, so the result is that of the sequential algorithm
- * (oracle/ransac_oracle.c).  F_out (may be NULL): the best matrix, pixels, x2^T F x1 = 0, row-major;
+ * (oracle/ransac_oracle.c).  Parity with OpenCV is UNPINNED here in one more respect: OpenCV's
+ * findFundamentalMat is believed to switch FM_RANSAC to LMedS below 15 point pairs (its source is
+ * not in the reference tree); this library runs threshold RANSAC for every m >= 7.
+ * F_out (may be NULL): the best matrix, pixels, x2^T F x1 = 0, row-major;
  * iters_out (may be NULL): hypotheses the adaptive loop examined.  Synchronous. */
 int gklt_relative_ransac(gklt_ctx *ctx, int n, const double *key_norm3, const double *cur_norm3,
                          const int *val, uint8_t *is_valid, const double *R, const double *K,

@@ -15,6 +15,8 @@
  *
  * What the reference does NOT fix: the RANSAC itself is cv::findFundamentalMat(FM_RANSAC), i.e.
  * OpenCV (not vendored, version unpinned, its own RNG and subset checks).  PARITY UNPINNED for it.
+ * (One more known difference: OpenCV is believed to replace FM_RANSAC by LMedS below 15 point
+ * pairs; this restatement and the GPU path run threshold RANSAC for every m >= 7.)
  * The algorithm below is OpenCV's published scheme -- 7-point minimal solver (null space of the
  * 7 x 9 epipolar system, cubic det(x f1 + f2) = 0), score = number of points whose larger
  * point-to-epipolar-line distance (squared, both images) is <= threshold^2, adaptive iteration count
