@@ -180,6 +180,7 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
     GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
     GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_chain_err), sizeof(unsigned), hipHostMallocDefault));
     *c->h_chain_err = 0;
+    if (const char *e = std::getenv("GKLT_CHAIN")) c->chain_levels = std::min(std::max(std::atoi(e), 0), 2);  // A/B runs
     return 0;
   }();
   if (rc) {  // release what the failed set-up had created (gklt_last_error keeps its message)
@@ -492,12 +493,12 @@ int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const 
     return 0;
   }
   // single frame, default kernels, every level an exact 2x decimation: levels 1 .. L-1 in one launch
-  bool chain = n == 1 && ctx->chain_levels && p0->nlevels >= 3 && (ctx->pyr_impl == 0 || ctx->pyr_impl == 2) &&
-               p0->chain_flags;
+  bool chain = (n == 1 ? ctx->chain_levels >= 1 : ctx->chain_levels >= 2) && p0->nlevels >= 3 &&
+               (ctx->pyr_impl == 0 || ctx->pyr_impl == 2) && p0->chain_flags;
   for (int l = 0; chain && l + 1 < p0->nlevels; ++l)
     chain = p0->lv[l].w == 2 * p0->lv[l + 1].w && p0->lv[l].h == 2 * p0->lv[l + 1].h;
   for (int l = 0; l < p0->nlevels; ++l) {
-    if (chain && l == 1) return launch_level_chain(ctx, s, py[0], t.pyr, t.gradg, t.gradd);
+    if (chain && l == 1) return launch_level_chain(ctx, s, py, n, t.pyr, t.gradg, t.gradd);
     const Level &a = p0->lv[l];
     const bool last = l + 1 == p0->nlevels;
     const bool exact = !last && a.w == 2 * p0->lv[l + 1].w && a.h == 2 * p0->lv[l + 1].h;
@@ -1003,7 +1004,7 @@ extern "C" int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves) {
 // bit-identical: inside north_star's 1e-4 relative tolerance; never the default)
 extern "C" int gklt_ctx_set_chain(gklt_ctx *ctx, int on) {
   if (!ctx) return GKLT_EINVAL;
-  ctx->chain_levels = on ? 1 : 0;
+  ctx->chain_levels = on < 0 ? 0 : (on > 2 ? 2 : on);
   return 0;
 }
 

@@ -92,7 +92,7 @@ struct gklt_ctx {
   gklt::HostStage stage_trk;       // gklt_track's list, invK and bearing vectors (s_trk's thread)
   std::atomic<unsigned long long> build_counter{0};  // source of gklt_pyramid::build_gen (unique per context)
   unsigned *h_chain_err = nullptr;  // page-locked word a k_level_chain tile raises when it gives up waiting
-  int chain_levels = 1;             // gklt_ctx_set_chain: 1 = coarse levels of a single-frame build in one launch
+  int chain_levels = 1;             // gklt_ctx_set_chain: 1 = coarse levels of single-frame builds in one launch, 2 = of batched builds too
   void *d_trk = nullptr;           // device image of stage_trk
   size_t d_trk_bytes = 0;
   gklt_flist *scratch_list = nullptr;
@@ -190,8 +190,8 @@ int launch_level_fma(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, cons
                  int n, int stride, int level, const Taps &s0, const Taps *pyr, const Taps &g,
                  const Taps &d, float *img0_out);
 // levels 1 .. L-1 of one pyramid in one launch (exact 2x decimations only)
-int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const Taps &pyr, const Taps &g,
-                       const Taps &d);
+int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, int n, const Taps &pyr,
+                       const Taps &g, const Taps &d);
 // streaming form of the fused level kernel (gklt_pyramid_stream.hip)
 bool level_streamable(int w, int h, int level, const Taps &s0);
 int launch_level_stream(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const uint8_t *const *src, int n,

@@ -793,25 +793,32 @@ __global__ __launch_bounds__(LNT) void k_level(LevelIO io, int stride, int w, in
 // wait for nothing later than themselves: every wait ends.  The wait is bounded all the same: a
 // tile that gives up raises *err (reported by the next synchronising call) instead of hanging.
 struct ChainArgs {
-  int nlev;                          // levels in the launch (pyramid levels 1 .. nlev)
-  int first_tile[GKLT_MAX_LEVELS];   // per launch level: first workgroup, tiles per row, size
+  int nlev, nframes;                 // levels in the launch (pyramid levels 1 .. nlev), frames of the batch
+  // per launch level: first workgroup of the level (all frames), tiles of ONE frame, first flag of
+  // the level inside a pyramid's flag array, tiles per row / column, size
+  int first_block[GKLT_MAX_LEVELS], tiles[GKLT_MAX_LEVELS], first_flag[GKLT_MAX_LEVELS];
   int tiles_x[GKLT_MAX_LEVELS], tiles_y[GKLT_MAX_LEVELS], w[GKLT_MAX_LEVELS], h[GKLT_MAX_LEVELS];
-  const float *img[GKLT_MAX_LEVELS];
-  Texel *tex[GKLT_MAX_LEVELS];
-  float *down[GKLT_MAX_LEVELS];      // nullptr for the last level
-  unsigned *flags;                   // one word per tile of the launch
-  unsigned epoch;
+  const float *img[GKLT_MAX_LOOKAHEAD][GKLT_MAX_LEVELS];  // img[f][i + 1] is where level i's decimated image goes
+  Texel *tex[GKLT_MAX_LOOKAHEAD][GKLT_MAX_LEVELS];
+  unsigned *flags[GKLT_MAX_LOOKAHEAD];  // one word per tile of the pyramid's levels 1 .. L-1
+  unsigned epoch[GKLT_MAX_LOOKAHEAD];
   unsigned *err;
 };
 
+// Workgroups are ordered level by level (all frames of level 1, then all frames of level 2, ...):
+// by the time a tile of level l is dispatched its producers were dispatched a whole level ago, and
+// in a batch the tiles of the next level fill the chip while the stragglers of this one finish.
 template <int RP, int RG, int LNT>
 __global__ __launch_bounds__(LNT) void k_level_chain(ChainArgs a, Taps pyr, Taps g, Taps d) {
   int li = 0;
   for (int i = 1; i < a.nlev; ++i)
-    if ((int)blockIdx.x >= a.first_tile[i]) li = i;
-  const int tile = blockIdx.x - a.first_tile[li];
+    if ((int)blockIdx.x >= a.first_block[i]) li = i;
+  const int local = blockIdx.x - a.first_block[li];
+  const int f = local / a.tiles[li], tile = local - f * a.tiles[li];
   const int tx = tile % a.tiles_x[li], ty = tile / a.tiles_x[li];
   const int x0 = tx * TW, y0 = ty * LTH, w = a.w[li], h = a.h[li];
+  unsigned *const flags = a.flags[f];
+  const unsigned epoch = a.epoch[f];
   if (li > 0) {
     // producers: tiles of the level above whose 32 x 16 outputs meet this tile's haloed input
     // (columns x0 - 8 .. x0 + 71, rows y0 - 5 .. y0 + 36, reflected into the image: inside it)
@@ -822,9 +829,9 @@ __global__ __launch_bounds__(LNT) void k_level_chain(ChainArgs a, Taps pyr, Taps
     if ((int)threadIdx.x < np) {
       const int pxx = min(px0 + (int)threadIdx.x % npx, a.tiles_x[li - 1] - 1);
       const int pyy = min(py0 + (int)threadIdx.x / npx, a.tiles_y[li - 1] - 1);
-      const unsigned *flag = a.flags + a.first_tile[li - 1] + pyy * a.tiles_x[li - 1] + pxx;
+      const unsigned *flag = flags + a.first_flag[li - 1] + pyy * a.tiles_x[li - 1] + pxx;
       int spins = 0;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
         if (++spins > (1 << 20)) {  // ~ a second: something is badly wrong; do not hang the GPU
           *a.err = 1u;
           break;
@@ -835,16 +842,17 @@ __global__ __launch_bounds__(LNT) void k_level_chain(ChainArgs a, Taps pyr, Taps
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
-  if (a.down[li])
-    level_tile<float, 0, RP, RG, true, LNT, true>(a.img[li], a.tex[li], a.down[li], w, w, h, g, pyr, g, d, nullptr,
-                                            a.w[li + 1 < a.nlev ? li + 1 : li], a.h[li + 1 < a.nlev ? li + 1 : li], x0, y0);
+  const bool down = li + 1 < a.nlev;
+  if (down)
+    level_tile<float, 0, RP, RG, true, LNT, true>(a.img[f][li], a.tex[f][li], const_cast<float *>(a.img[f][li + 1]), w,
+                                                  w, h, g, pyr, g, d, nullptr, a.w[li + 1], a.h[li + 1], x0, y0);
   else
-    level_tile<float, 0, RP, RG, false, LNT>(a.img[li], a.tex[li], nullptr, w, w, h, g, g, g, d, nullptr, 0, 0, x0, y0);
-  if (a.down[li]) {
+    level_tile<float, 0, RP, RG, false, LNT>(a.img[f][li], a.tex[f][li], nullptr, w, w, h, g, g, g, d, nullptr, 0, 0, x0, y0);
+  if (down) {
     __builtin_amdgcn_s_waitcnt(0);  // this wavefront's write-through stores have been acknowledged
     __syncthreads();
     if (threadIdx.x == 0)
-      __hip_atomic_store(a.flags + blockIdx.x, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flags + a.first_flag[li] + tile, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1077,33 +1085,47 @@ int launch_level(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, const ui
 }
 
 #ifndef GKLT_PYR_FMA
-// Levels 1 .. L-1 of one pyramid in one launch (k_level_chain); the caller has checked that every
-// level is an exact 2x decimation of the one above and that the radii are the fused kernels'.
-int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const Taps &pyr, const Taps &g,
-                       const Taps &d) {
+// Levels 1 .. L-1 of n same-sized pyramids in one launch (k_level_chain); the caller has checked
+// that every level is an exact 2x decimation of the one above and that the radii are the fused kernels'.
+int launch_level_chain(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py, int n, const Taps &pyr,
+                       const Taps &g, const Taps &d) {
+  if (n < 1 || n > GKLT_MAX_LOOKAHEAD) return GKLT_EINVAL;
   ChainArgs a{};
-  a.nlev = py->nlevels - 1;
-  if (a.nlev < 1 || !py->chain_flags) return GKLT_EINVAL;
-  int tiles = 0;
+  const gklt_pyramid *p0 = py[0];
+  a.nlev = p0->nlevels - 1;
+  a.nframes = n;
+  if (a.nlev < 1) return GKLT_EINVAL;
+  int blocks = 0, nflags = 0;
   for (int i = 0; i < a.nlev; ++i) {
-    const Level &L = py->lv[i + 1];
-    a.first_tile[i] = tiles;
+    const Level &L = p0->lv[i + 1];
     a.tiles_x[i] = (L.w + TW - 1) / TW;
     a.tiles_y[i] = (L.h + LTH - 1) / LTH;
+    a.tiles[i] = a.tiles_x[i] * a.tiles_y[i];
+    a.first_block[i] = blocks;
+    a.first_flag[i] = nflags;
     a.w[i] = L.w;
     a.h[i] = L.h;
-    a.img[i] = L.img;
-    a.tex[i] = L.tex;
-    a.down[i] = i + 1 < a.nlev ? py->lv[i + 2].img : nullptr;
-    tiles += a.tiles_x[i] * a.tiles_y[i];
+    blocks += n * a.tiles[i];
+    nflags += a.tiles[i];
   }
-  if (tiles > py->chain_tiles) return GKLT_EINVAL;
-  a.flags = py->chain_flags;
-  a.epoch = ++py->chain_epoch;
+  for (int f = 0; f < n; ++f) {
+    gklt_pyramid *q = py[f];
+    if (!q->chain_flags || nflags > q->chain_tiles || q->nlevels != p0->nlevels) return GKLT_EINVAL;
+    for (int i = 0; i < a.nlev; ++i) {
+      if (q->lv[i + 1].w != a.w[i] || q->lv[i + 1].h != a.h[i]) return GKLT_EINVAL;
+      a.img[f][i] = q->lv[i + 1].img;
+      a.tex[f][i] = q->lv[i + 1].tex;
+    }
+    a.flags[f] = q->chain_flags;
+    a.epoch[f] = ++q->chain_epoch;
+  }
   a.err = ctx->h_chain_err;
   constexpr size_t lds = level_lds<0, 5, 3, true>();
   ProfScope ps(ctx, s, GKLT_K_LEVELN);
-  hipLaunchKernelGGL((k_level_chain<5, 3, 512>), dim3(tiles), dim3(512), lds, s, a, pyr, g, d);
+  if (n > 1)  // batched: 4-wave workgroups, as the per-level launches (see LTH)
+    hipLaunchKernelGGL((k_level_chain<5, 3, 256>), dim3(blocks), dim3(256), lds, s, a, pyr, g, d);
+  else
+    hipLaunchKernelGGL((k_level_chain<5, 3, 512>), dim3(blocks), dim3(512), lds, s, a, pyr, g, d);
   GKLT_HIP(hipGetLastError());
   return 0;
 }
