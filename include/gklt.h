@@ -464,8 +464,9 @@ int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
  * flags of a few features per thousand differ in the last digits.  Never the default. */
 int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
 /* A/B switch (default 1): a single-frame build runs levels 1 .. L-1 in ONE launch whose tiles wait
- * for the tiles of the level above through per-tile flags, instead of one launch per level.  Same
- * results. */
+ * for the tiles of the level above through per-tile flags, instead of one launch per level
+ * (0: one launch per level; 2: batched builds take the chained launch too -- measured slower).
+ * Same results. */
 int gklt_ctx_set_chain(gklt_ctx *ctx, int on);
 /* Suppression rounds of the selectors (plain / ...2, and the uncapped phase of the Uniform one):
  * 0 (default) = rounds on box tops -- one candidate per (r+1) x (r+1) box is examined instead of
