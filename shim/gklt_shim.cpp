@@ -19,6 +19,8 @@
 #include <gklt.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -234,6 +236,11 @@ KLT_TrackingContext KLTCreateTrackingContext() {  // KLTUtil.cpp:298-342, defaul
 // reference the call returns when the pyramid is complete; it is meant to run on the preload
 // thread (System.cpp:370-373,508-511).  Define GKLT_SHIM_ALL_PLANES to materialise every plane.
 void computePyramid(KLT_TrackingContext tc, const cv::Mat &img, std::vector<cv::Mat> &pyramid) {
+  // GKLT_SHIM_BREAKDOWN=1: mean time of the call's three parts on stderr, every 64 calls
+  static const bool breakdown = std::getenv("GKLT_SHIM_BREAKDOWN") != nullptr;
+  static double t_parts[3] = {0, 0, 0};
+  static int t_calls = 0;
+  const auto q0 = std::chrono::steady_clock::now();
   gklt_ctx *ctx = push(tc);
   PyramidEntry e;
   {
@@ -247,7 +254,9 @@ void computePyramid(KLT_TrackingContext tc, const cv::Mat &img, std::vector<cv::
     std::lock_guard<std::mutex> lk(g_mu);
     g_pyr[&pyramid] = e;
   }
+  const auto q1 = std::chrono::steady_clock::now();
   check(gklt_pyramid_build(ctx, e.py, img.data, (int)img.step, /*img_on_device=*/0));
+  const auto q2 = std::chrono::steady_clock::now();
   pyramid.resize(3 * (size_t)tc->nPyramidLevels);
   for (int i = 0; i < 3 * tc->nPyramidLevels; ++i) {
 #ifndef GKLT_SHIM_ALL_PLANES
@@ -258,6 +267,18 @@ void computePyramid(KLT_TrackingContext tc, const cv::Mat &img, std::vector<cv::
     pyramid[i].create(h, w, CV_32F);
     check(gklt_pyramid_download(ctx, e.py, i / 3, i % 3, reinterpret_cast<float *>(pyramid[i].data),
                                 (int)(pyramid[i].step / sizeof(float))));
+  }
+  if (breakdown) {
+    const auto q3 = std::chrono::steady_clock::now();
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::micro>(b - a).count();
+    };
+    t_parts[0] += us(q0, q1); t_parts[1] += us(q1, q2); t_parts[2] += us(q2, q3);
+    if (++t_calls % 64 == 0) {
+      std::fprintf(stderr, "computePyramid: set-up %.1f us, gklt_pyramid_build (enqueue) %.1f us, plane download (waits for the build) %.1f us\n",
+                   t_parts[0] / 64, t_parts[1] / 64, t_parts[2] / 64);
+      t_parts[0] = t_parts[1] = t_parts[2] = 0;
+    }
   }
 }
 

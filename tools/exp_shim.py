@@ -3,6 +3,7 @@
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["GKLT_DRV_BREAKDOWN"] = "1"
+os.environ["GKLT_SHIM_BREAKDOWN"] = "1"
 from gslam_amd import klt, synth
 import bench
 klt.lib()
