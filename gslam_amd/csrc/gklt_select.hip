@@ -782,6 +782,7 @@ constexpr int kTopsW = 64, kTopsH = 32, kTopsT = 256;
 constexpr size_t kTopsMaxLds = 64 * 1024;
 #endif
 constexpr unsigned long long kOnes = ~0ull;
+constexpr int kTopsCellRows = 8;  // Uniform flavour: cell rows a haloed tile may meet (field table in LDS)
 struct TopsGeom {
   int B, nbx, nby, cw, ch, inw, inh, ng, S;
 };
@@ -800,7 +801,7 @@ __host__ __device__ inline TopsGeom tops_geom(int r) {
 }
 inline size_t tops_lds_bytes(int r) {
   const TopsGeom g = tops_geom(r);
-  return 8 * (size_t)g.inh * g.S + 2 * (size_t)(4 * g.ng + g.inh);
+  return 8 * (size_t)g.inh * g.S + 2 * (size_t)((1 + kTopsCellRows) * 4 * g.ng + g.inh);
 }
 // boxes of fewer than 5 x 5 pixels leave a wavefront mostly idle (and a tile would hold more boxes
 // than a wavefront's open-box mask has bits): those radii keep the dense rounds
@@ -865,7 +866,8 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
   const int B = G.B, S = G.S, WW = 2 * r + 1;
   unsigned long long *key = ldsk;  // inh x S
   unsigned short *colcell = reinterpret_cast<unsigned short *>(key + G.inh * S);  // UNI: cell column of a tile column
-  unsigned short *rowcell = colcell + 4 * G.ng;                                   //      cell row of a tile row
+  [[maybe_unused]] unsigned short *colfld = colcell + 4 * G.ng;                   //      fields, [cell row][tile column]
+  unsigned short *rowcell = colfld + kTopsCellRows * 4 * G.ng;                    //      cell row of a tile row
   __shared__ unsigned blk_left[3];
   __shared__ int blk_changed[3];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -907,12 +909,13 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
     blk_left[0] = blk_left[1] = blk_left[2] = 0;
     blk_changed[0] = blk_changed[1] = blk_changed[2] = 0;
   }
-  // UNI: visiting ranks of the grid cells that meet the haloed tile, in LDS when they are few
-  constexpr int kCells = 64;
-  __shared__ unsigned short crank[kCells];
-  int cx0 = 0, cy0 = 0, ncx = 0;  // ncx == 0: too many cells, ranks are read from the global table
+  // UNI: the priority field of every (cell row of the tile, tile column), so that a pixel's field is
+  // ONE LDS read (four adjacent pixels: one 8-byte read) instead of cell lookups and a rank load
+  // per pixel -- two dependent memory round trips per pixel made staging the longest part of a
+  // launch.  The host takes this kernel only when a haloed tile meets at most kTopsCellRows cell rows.
+  int cy0 = 0;
+  const int ncol = 4 * G.ng;
   if constexpr (UNI) {
-    const int ncol = 4 * G.ng;
     for (int t = tid; t < ncol + G.inh; t += kTopsT) {
       if (t < ncol)
         colcell[t] = (unsigned short)min(min(max(x0 - r + t, 0), w - 1) / ug.gw, ug.cw - 1);
@@ -920,22 +923,21 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
         rowcell[t - ncol] = (unsigned short)min(min(max(y0 - r + t - ncol, 0), h - 1) / ug.gh, ug.ch - 1);
     }
     __syncthreads();
-    cx0 = colcell[0];
     cy0 = rowcell[0];
-    const int nx = colcell[ncol - 1] - cx0 + 1, ny = rowcell[G.inh - 1] - cy0 + 1;
-    if (nx * ny <= kCells) {
-      ncx = nx;
-      if (tid < nx * ny) crank[tid] = ug.rank[(cy0 + tid / nx) * ug.cw + cx0 + tid % nx];
+    for (int t = tid; t < kTopsCellRows * ncol; t += kTopsT) {
+      const int rr = t / ncol, c = t - rr * ncol;
+      colfld[t] = (unsigned short)(0xFFFFu - ug.rank[min(cy0 + rr, ug.ch - 1) * ug.cw + colcell[c]]);
     }
     __syncthreads();
   }
-  // key of an undecided candidate with score sc at tile position (tx, ty); rowbase: see below
-  auto make_key = [&](unsigned sc, int tx, int ty, int rowbase) -> unsigned long long {
-    unsigned fld = 0;
-    if constexpr (UNI)
-      fld = 0xFFFFu - (ncx ? crank[rowbase + colcell[tx]] : ug.rank[rowcell[ty] * ug.cw + colcell[tx]]);
-    return ((unsigned long long)fld << 48) | ((unsigned long long)sc << 16) |
-           (unsigned long long)((0xFF - ty) << 8 | (0xFF - tx));
+  // 64-bit key of a map entry sv at tile position (tx, ty): 0 = nothing to decide, all ones = accepted,
+  // else (field, score, 255 - ty, 255 - tx); branch-free
+  auto make_key = [&](unsigned sv, unsigned fld, int tx, int ty) -> unsigned long long {
+    unsigned hi = (fld << 16) | (sv >> 16), lo = (sv << 16) | (unsigned)((0xFF - ty) << 8 | (0xFF - tx));
+    const bool acc = (sv & kAccepted) != 0;
+    hi = sv == 0 ? 0u : (acc ? 0xFFFFFFFFu : hi);
+    lo = sv == 0 ? 0u : (acc ? 0xFFFFFFFFu : lo);
+    return ((unsigned long long)hi << 32) | lo;
   };
   // Staging.  A tile whose staged columns (rounded up to whole groups) lie inside the image loads
   // four pixels per load, all loads of a thread in flight together; the others (left and right
@@ -966,17 +968,14 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
           const int ty = g / G.ng, gx = g - ty * G.ng;
           const int y = y0 - r + ty;
           const bool yin = y >= 0 && y < h;
-          int rowbase = 0;
-          if constexpr (UNI) rowbase = (rowcell[ty] - cy0) * ncx - cx0;
+          unsigned long long f4 = 0ull;  // the four pixels' fields, 16 bits each
+          if constexpr (UNI)
+            f4 = *reinterpret_cast<const unsigned long long *>(
+                colfld + min((int)rowcell[ty] - cy0, kTopsCellRows - 1) * ncol + 4 * gx);
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {  // columns inw .. 4 ng - 1 are staged too and never read
-            const int tx = 4 * gx + k;
-            const unsigned sv = yin ? q[u].v[k] : 0u;
-            unsigned long long kk = 0ull;
-            if (sv & kAccepted) kk = kOnes;
-            else if (sv != 0) kk = make_key(sv, tx, ty, rowbase);
-            key[ty * S + tx] = kk;
-          }
+          for (int k = 0; k < 4; ++k)  // columns inw .. 4 ng - 1 are staged too and never read
+            key[ty * S + 4 * gx + k] =
+                make_key(yin ? q[u].v[k] : 0u, (unsigned)(f4 >> (16 * k)) & 0xFFFFu, 4 * gx + k, ty);
         }
       }
     }
@@ -1004,16 +1003,10 @@ __global__ __launch_bounds__(kTopsT) void k_tops_round(unsigned *__restrict__ st
       if (i < total) {
         const int ty = i / G.inw, tx = i - ty * G.inw;
         const int x = x0 - r + tx, y = y0 - r + ty;
-        const unsigned s = (x >= 0 && x < w && y >= 0 && y < h) ? sv[u] : 0u;
-        unsigned long long k = 0ull;
-        if (s & kAccepted) {
-          k = kOnes;
-        } else if (s != 0) {
-          int rowbase = 0;
-          if constexpr (UNI) rowbase = (rowcell[ty] - cy0) * ncx - cx0;
-          k = make_key(s, tx, ty, rowbase);
-        }
-        key[ty * S + tx] = k;
+        const unsigned sx = (x >= 0 && x < w && y >= 0 && y < h) ? sv[u] : 0u;
+        unsigned fld = 0;
+        if constexpr (UNI) fld = colfld[min((int)rowcell[ty] - cy0, kTopsCellRows - 1) * ncol + tx];
+        key[ty * S + tx] = make_key(sx, fld, tx, ty);
       }
     }
   }
@@ -1889,7 +1882,8 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   // centre-out order is 93 cells on the 60 x 33 grid of a 1080p frame, and a lone wavefront needs
   // several microseconds per cell: 12 ms, against 0.64 ms for these rounds.)
   const int tcx = (MW + 2 * r - 2) / gridW + 2, tcy = (MH + 2 * r - 2) / gridH + 2;
-  const int keys = ctx->sel_impl == 0 && tops_usable(r) ? kUniTops
+  // (box rounds: the tile's field table holds kTopsCellRows cell rows)
+  const int keys = ctx->sel_impl == 0 && tops_usable(r) && (tops_geom(r).inh - 1) / gridH + 2 <= kTopsCellRows ? kUniTops
                    : ctx->sel_impl != 1 && tcx * tcy <= kU32Cells ? kUniKeys32 : kUniKeys64;
   const bool keys32 = keys == kUniKeys32;
   // The accepted candidates are collected behind every batch of rounds, so that their number
