@@ -76,6 +76,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0 = auto)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_inclusive legs")
     ap.add_argument("--no-shim", action="store_true", help="skip the shim_drop_in block")
+    ap.add_argument("--select-scores", default="integral", choices=["integral", "direct"],
+                    help="C5: candidate scores from fp32 integral images (the reference's inputs) or from window "
+                         "sums formed directly (SURVEY section 7's fast path; gklt_ctx_set_select_scores)")
     ap.add_argument("--no-select-prepare", action="store_true",
                     help="C5: compute the integral images inside the selection (no gklt_select_prepare)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
@@ -677,7 +680,7 @@ def main_c5(a, ctx, cfg, dist, rank, world):
             cur, nxt = ring[t % 3], ring[(t + 1) % 3]
             ptr, stride, _ = store.frame(t + 1)
             nxt.build_from_device(ptr, stride)
-            if not a.no_select_prepare:   # integral images of frame t+1 behind its build, beside select(t)
+            if prepare:   # integral images of frame t+1 behind its build, beside select(t)
                 klt.select_prepare(ctx, nxt)
             klt.select_from_pyramid(ctx, cur, klt.SELECT_ALL, variant, fl, grid=sel["grid"])
             klt.track_flist(ctx, cur, nxt, fl)
@@ -690,6 +693,21 @@ def main_c5(a, ctx, cfg, dist, rank, world):
 
     ptr, stride, _ = store.frame(0)
     ring[0].build_from_device(ptr, stride)
+    # how far the two score forms agree ("selection overlap"): one selection of
+    # n slots each way on frame 0, outside the timed region
+    picks = []
+    probe = klt.FeatureList(ctx, 100 * n)
+    for mode in (0, 1):
+        ctx.set_select_scores(mode)
+        probe.upload(*empty)
+        klt.select_from_pyramid(ctx, ring[0], klt.SELECT_ALL, variant, probe, grid=sel["grid"])
+        px, py_, pv = probe.download()
+        picks.append({(x, y) for x, y, v in zip(px, py_, pv) if v > 0})
+    probe.close()
+    overlap = len(picks[0] & picks[1]) / max(len(picks[0] | picks[1]), 1)
+    direct = a.select_scores == "direct"
+    ctx.set_select_scores(1 if direct else 0)
+    prepare = not a.no_select_prepare and not direct
     run(a.warmup)
     ctx.sync()
     fl.stats(reset=True)
@@ -762,6 +780,11 @@ def main_c5(a, ctx, cfg, dist, rank, world):
                    "tracked_fraction": tracked_all / (world * a.steps * max(nlist, 1)),
                    "newton_iters_per_feature_frame": iters_all / (world * a.steps * max(nlist, 1)),
                    "suppression_launches_last_selection": {"phase_a": rounds[0], "phase_b": rounds[1]},
+                   "select_scores": a.select_scores,
+                   "selection_overlap_direct_vs_integral": {
+                       "jaccard": overlap, "selected_integral": len(picks[0]), "selected_direct": len(picks[1]),
+                       "what": "one selection on frame 0 with scores from integral images and one with direct "
+                               "window sums: |A & B| / |A | B| of the selected positions"},
                    "parallelism": "stream-sharded x%d, no collective" % world},
         "latency_ms": {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
                        "mode": "build(t+1) + select(t) + track(t -> t+1) enqueued -> both streams drained"},

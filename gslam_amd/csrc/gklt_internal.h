@@ -107,6 +107,7 @@ struct gklt_ctx {
   int track_waves = 0;  // wavefronts per tracker launch (0 = default cap)
   int sel_impl = 0;         // suppression rounds: 0 = box tops (dense 32-bit keys where the radius rules them out), 1 = dense 64-bit keys, 2 = dense 32-bit keys
   int sel_local_iters = 3;  // selector: fixpoint iterations per tile and launch (dense rounds)
+  int sel_scores = 0;       // gklt_ctx_set_select_scores: 0 = integral images (the reference's inputs), 1 = direct window sums
   int sel_tops_iters = 12;  // the same for the rounds on box tops, whose iterations cost less
   int track_impl = 0;  // 0 = one feature per wavefront, 1 = one feature per 8-lane slice
   bool profiling = false;

@@ -154,6 +154,25 @@ __global__ __launch_bounds__(256) void k_integral_cols(float *__restrict__ sxx,
 }
 
 // ------------------------------------------------------------------ S1 score
+// candidate score from the three window sums: _minEigenvalue (:220-223), threshold and int
+// conversion of the plain (:351-361) and rounding (:737-740) flavours; 0 = not a candidate
+__device__ __forceinline__ unsigned score_from_sums(float gxx, float gyy, float gxy, int min_eig,
+                                                    int round2, int score_max) {
+  const float v = (gxx + gyy - sqrtf((gxx - gyy) * (gxx - gyy) + 4 * gxy * gxy)) / 2.0f;
+  int iv = 0;
+  if (round2) {
+    if (v >= 2147483648.0f) iv = 0x7fffffff;
+    else if (v > -2147483648.0f) iv = (int)((double)v + 0.5);  // :737
+    if (!(iv > min_eig)) iv = 0;                                 // :740
+  } else {
+    if (v > (float)min_eig) iv = v >= 2147483648.0f ? 0x7fffffff : (int)v;  // :351-361
+  }
+  // _enforceMinimumDistance only ever accepts val >= max(1, min_eigenvalue) (:103-104,175)
+  // score_max: INT_MAX, or INT_MAX - 1 for the Uniform selector, where INT_MAX marks a surviving
+  // feature (:1132,1232) and the oracle documents the clamp one below it
+  return (iv >= 1 && iv >= min_eig) ? (unsigned)min(iv, score_max) : 0u;
+}
+
 // state[y*w+x] = score (1..INT_MAX) of an emitted candidate, else 0.
 // selectGoodFeatures.hpp:324-366 (plain), :707-751 (rounding flavour).
 __global__ void k_score(const float *__restrict__ sxx, const float *__restrict__ syy,
@@ -172,22 +191,69 @@ __global__ void k_score(const float *__restrict__ sxx, const float *__restrict__
     const float gxy = sxy[r0 + x1] + sxy[r1 + x2] - sxy[r1 + x1] - sxy[r0 + x2];
     const float gxx = sxx[r0 + x1] + sxx[r1 + x2] - sxx[r1 + x1] - sxx[r0 + x2];
     const float gyy = syy[r0 + x1] + syy[r1 + x2] - syy[r1 + x1] - syy[r0 + x2];
-    // _minEigenvalue, :220-223
-    const float v = (gxx + gyy - sqrtf((gxx - gyy) * (gxx - gyy) + 4 * gxy * gxy)) / 2.0f;
-    int iv = 0;
-    if (round2) {
-      if (v >= 2147483648.0f) iv = 0x7fffffff;
-      else if (v > -2147483648.0f) iv = (int)((double)v + 0.5);  // :737
-      if (!(iv > min_eig)) iv = 0;                                 // :740
-    } else {
-      if (v > (float)min_eig) iv = v >= 2147483648.0f ? 0x7fffffff : (int)v;  // :351-361
-    }
-    // _enforceMinimumDistance only ever accepts val >= max(1, min_eigenvalue) (:103-104,175)
-    // score_max: INT_MAX, or INT_MAX - 1 for the Uniform selector, where INT_MAX marks a surviving
-    // feature (:1132,1232) and the oracle documents the clamp one below it
-    if (iv >= 1 && iv >= min_eig) out = (unsigned)min(iv, score_max);
+    out = score_from_sums(gxx, gyy, gxy, min_eig, round2, score_max);
   }
   state[(size_t)y * w + x] = out;
+}
+
+// ---- S1 without integral images (SURVEY section 7's fast path; no counterpart in the reference,
+// whose selector API takes the integral images): the window sums of gx^2, gy^2, gx gy formed
+// directly from the level's texels by a separable box sum -- each window row left to right, the row
+// sums top to bottom (oracle: ok_box_products) -- so there is no cancellation between sums ~1e9 and
+// no serial prefix chain.  Scores differ from the integral-image ones in the last bits; selections
+// are compared by set overlap, and bit for bit with the oracle's direct form.
+constexpr int kDW = 64, kDH = 16, kDMaxHalf = 16;
+__global__ __launch_bounds__(256) void k_score_direct(const Texel *__restrict__ tex,
+                                                      const unsigned char *__restrict__ blocked, int w,
+                                                      int h, int hw, int hh, int bx, int by, int step,
+                                                      int min_eig, int round2, int score_max,
+                                                      unsigned *__restrict__ state) {
+  extern __shared__ __align__(16) float ldsf[];
+  const int inW = kDW + 2 * hw, inH = kDH + 2 * hh, PW = inW | 1;
+  float *P = ldsf;                 // [3][inH][PW] products
+  float *Rs = P + 3 * inH * PW;    // [3][inH][kDW + 1] row sums
+  const int x0 = blockIdx.x * kDW, y0 = blockIdx.y * kDH;
+  for (int i = threadIdx.x; i < inW * inH; i += 256) {
+    const int ty = i / inW, tx = i - ty * inW;
+    const int x = min(max(x0 - hw + tx, 0), w - 1), y = min(max(y0 - hh + ty, 0), h - 1);
+    const Texel t = tex[(size_t)y * w + x];
+    P[(0 * inH + ty) * PW + tx] = t.y * t.y;  // cv::multiply, System.cpp:386-388
+    P[(1 * inH + ty) * PW + tx] = t.z * t.z;
+    P[(2 * inH + ty) * PW + tx] = t.y * t.z;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * inH * kDW; i += 256) {
+    const int q = i / (inH * kDW), rem = i - q * inH * kDW, ty = rem / kDW, tx = rem - ty * kDW;
+    const float *p = P + (q * inH + ty) * PW + tx;
+    float acc = p[0];
+    for (int d = 1; d <= 2 * hw; ++d) acc = acc + p[d];
+    Rs[(q * inH + ty) * (kDW + 1) + tx] = acc;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kDW * kDH; i += 256) {
+    const int ty = i / kDW, tx = i - ty * kDW;
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= w || y >= h) continue;
+    unsigned out = 0;
+    const bool on_grid = x >= bx && x < w - bx && y >= by && y < h - by &&
+                         (x - bx) % step == 0 && (y - by) % step == 0;
+    if (on_grid && !(blocked && blocked[(size_t)y * w + x])) {
+      float sum[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float *p = Rs + (q * inH + ty) * (kDW + 1) + tx;
+        float acc = p[0];
+        for (int d = 1; d <= 2 * hh; ++d) acc = acc + p[d * (kDW + 1)];
+        sum[q] = acc;
+      }
+      out = score_from_sums(sum[0], sum[1], sum[2], min_eig, round2, score_max);
+    }
+    state[(size_t)y * w + x] = out;
+  }
+}
+inline size_t score_direct_lds(int hw, int hh) {
+  const size_t inW = kDW + 2 * hw, inH = kDH + 2 * hh;
+  return sizeof(float) * 3 * inH * ((inW | 1) + kDW + 1);
 }
 
 // featuremap pre-fill for surviving features when replacing (:280-288): radius mindist
@@ -1258,6 +1324,7 @@ struct SelScratch {
   hipEvent_t pre_done[2] = {nullptr, nullptr};
   int pre_next = 0;
   float *const *active = nullptr;  // the set the selection in progress reads (sum or pre[k])
+  const Texel *direct_tex = nullptr;  // non-null: scores from direct window sums of these texels
   unsigned *state = nullptr;
   unsigned char *blocked = nullptr;
   unsigned long long *list = nullptr;
@@ -1353,6 +1420,7 @@ static int sel_get(gklt_ctx *ctx, int w, int h, int nslots, SelScratch **out) {
   s->w = w;
   s->h = h;
   s->active = s->sum;
+  s->direct_tex = nullptr;
   s->cap_list = (int)px;  // mindist 1 accepts every candidate
   s->ntiles = s->cap_tiles;  // the two halves of tile_changed lie cap_tiles apart
   s->tile_bytes = sizeof(unsigned) * s->cap_tiles;
@@ -1378,6 +1446,10 @@ int select_integrals_from_pyramid(gklt_ctx *ctx, hipStream_t s, const gklt_pyram
 // Integral images of level 0 for the selection on `py`: the set gklt_select_prepare computed ahead
 // (the tracker stream then only waits for it), else computed now on stream s.
 static int select_sums_for(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *py, SelScratch *sc) {
+  if (ctx->sel_scores == 1 && ctx->prm.window_width / 2 <= kDMaxHalf && ctx->prm.window_height / 2 <= kDMaxHalf) {
+    sc->direct_tex = py->lv[0].tex;  // no integral images at all
+    return 0;
+  }
   for (int k = 0; k < 2; ++k)
     if (sc->pre_py[k] == py && sc->pre_gen[k] == py->build_gen && sc->pre[k][0]) {
       GKLT_HIP(hipStreamWaitEvent(s, sc->pre_done[k], 0));
@@ -1387,6 +1459,23 @@ static int select_sums_for(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *py,
     }
   sc->active = sc->sum;
   return select_integrals_from_pyramid(ctx, s, py, sc);
+}
+
+// the score pass of a selection: from the active integral images, or directly from the texels
+static void launch_score(hipStream_t s, SelScratch *sc, const unsigned char *blocked, int hw, int hh,
+                         int bx, int by, int step, int min_eig, int round2, int score_max,
+                         unsigned *dst) {
+  const int w = sc->w, h = sc->h;
+  if (sc->direct_tex && score_direct_lds(hw, hh) > 48 * 1024)  // (at most 93 KB: halves <= kDMaxHalf)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_score_direct),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)score_direct_lds(hw, hh));
+  if (sc->direct_tex)
+    hipLaunchKernelGGL(k_score_direct, dim3((w + kDW - 1) / kDW, (h + kDH - 1) / kDH), dim3(256),
+                       score_direct_lds(hw, hh), s, sc->direct_tex, blocked, w, h, hw, hh, bx, by, step,
+                       min_eig, round2, score_max, dst);
+  else
+    hipLaunchKernelGGL(k_score, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->active[0], sc->active[1],
+                       sc->active[2], blocked, w, h, hw, hh, bx, by, step, min_eig, round2, score_max, dst);
 }
 
 // S1-S4 on device-resident sums and a device-resident list (x, y, val of n features).
@@ -1416,9 +1505,8 @@ int select_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int mode, int
   }
   {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    hipLaunchKernelGGL(k_score, dim3((w + 255) / 256, h), dim3(256), 0, s, sc->active[0], sc->active[1],
-                       sc->active[2], overwrite ? (const unsigned char *)nullptr : sc->blocked, w, h,
-                       hw, hh, bx, by, step, P.min_eigenvalue, round2, 0x7fffffff, sc->state);
+    launch_score(s, sc, overwrite ? (const unsigned char *)nullptr : sc->blocked, hw, hh, bx, by, step,
+                 P.min_eigenvalue, round2, 0x7fffffff, sc->state);
   }
   hipLaunchKernelGGL(k_lost_slots, dim3(1), dim3(1024), 0, s, fval, n, overwrite, sc->slots,
                      sc->nslots);
@@ -1867,9 +1955,7 @@ int select_uniform_on_device(gklt_ctx *ctx, hipStream_t s, SelScratch *sc, int g
   // costs no copy of the map
   auto score_into = [&](unsigned *dst) {
     ProfScope ps(ctx, s, GKLT_K_SELECT);
-    hipLaunchKernelGGL(k_score, pgrid, dim3(256), 0, s, sc->active[0], sc->active[1], sc->active[2],
-                       (const unsigned char *)nullptr, w, h, hw, hh, bx, by, step,
-                       P.min_eigenvalue, 0, 0x7ffffffe, dst);
+    launch_score(s, sc, nullptr, hw, hh, bx, by, step, P.min_eigenvalue, 0, 0x7ffffffe, dst);
   };
   score_into(sc->state);
 
@@ -1995,6 +2081,12 @@ extern "C" int gklt_ctx_set_select_iters(gklt_ctx *ctx, int iters) {
 extern "C" int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 2) return GKLT_EINVAL;
   ctx->sel_impl = impl;
+  return 0;
+}
+
+extern "C" int gklt_ctx_set_select_scores(gklt_ctx *ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 1) return GKLT_EINVAL;
+  ctx->sel_scores = mode;
   return 0;
 }
 
@@ -2207,7 +2299,10 @@ extern "C" int gklt_seed_from_level(gklt_ctx *ctx, gklt_pyramid *py, int level, 
   if (int rc = sel_get(ctx, py->lv[level].w, py->lv[level].h, nFeatures, &sc)) return rc;
   hipStream_t s = ctx->s_trk;
   GKLT_HIP(hipStreamWaitEvent(s, py->ready, 0));
-  if (int rc = select_integrals_from_pyramid(ctx, s, py, sc, level)) return rc;
+  if (ctx->sel_scores == 1 && P.window_width / 2 <= kDMaxHalf && P.window_height / 2 <= kDMaxHalf)
+    sc->direct_tex = py->lv[level].tex;
+  else if (int rc = select_integrals_from_pyramid(ctx, s, py, sc, level))
+    return rc;
   if (int rc = select_on_device(ctx, s, sc, GKLT_SELECT_ALL, 0, nFeatures, fl->x, fl->y, fl->val, &P))
     return rc;
   hipLaunchKernelGGL(k_seed_scale, dim3((nFeatures + 255) / 256), dim3(256), 0, s, fl->x, fl->y, fl->val,

@@ -163,6 +163,9 @@ class Context:
         """Plain selector rounds: 0 = 32-bit keys (default), 1 = 64-bit keys."""
         _check(lib().gklt_ctx_set_select_impl(self.h, int(impl)))
 
+    def set_select_scores(self, mode):
+        _check(lib().gklt_ctx_set_select_scores(self.h, int(mode)))
+
     def set_select_iters(self, iters):
         """Fixpoint iterations per tile and suppression launch of the selector (default 3)."""
         _check(lib().gklt_ctx_set_select_iters(self.h, int(iters)))

@@ -473,6 +473,14 @@ int gklt_ctx_set_chain(gklt_ctx *ctx, int on);
  * every pixel -- for radii 4..~45, dense rounds on 32-bit keys otherwise; 1 = dense rounds on
  * 64-bit keys; 2 = dense rounds on 32-bit keys.  Identical results. */
 int gklt_ctx_set_select_impl(gklt_ctx *ctx, int impl);
+/* Candidate scores of gklt_select_from_pyramid / gklt_seed_from_level: 0 (default) = from fp32
+ * integral images in cv::integral's order, i.e. what the reference's selector is handed
+ * (System.cpp:385-392); 1 = from window sums formed directly (separable box sum of gx^2, gy^2,
+ * gx gy over the window: each window row left to right, the row sums top to bottom) -- no
+ * counterpart in the reference: no integral images, no cancellation between sums ~1e9, windows up
+ * to 33 px.  Scores then differ from mode 0 in the last bits, so selections are compared by set
+ * overlap (bench.py --config C5 reports it); against the oracle's direct form they are identical. */
+int gklt_ctx_set_select_scores(gklt_ctx *ctx, int mode);
 /* Selector: fixpoint iterations a tile runs in LDS per suppression launch (1..64; default 3 for the
  * dense rounds, 12 for the rounds on box tops; 1 = one iteration per launch).  Results do not
  * depend on it. */

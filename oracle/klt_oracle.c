@@ -612,13 +612,58 @@ static float min_eigenvalue(float gxx, float gxy, float gyy) { /* :220-223 */
 /* candidate score at (x,y); returns 0 if not emitted.  :341-364 (plain), :725-749 (ROUND2).
  * A score above INT_MAX is clamped to INT_MAX (the reference converts 2^31 to int, which is
  * undefined; unreachable for 8-bit imagery). */
+/* Direct window sums ("compute window sums directly ... separable box filter on
+ * gx^2, gy^2, gx gy"; not in the reference, whose selector takes integral images).  When set, the
+ * candidate score is formed from these H x W planes of window sums instead of four integral-image
+ * taps: no cancellation between sums ~1e9.  ok_box_products defines the summation order. */
+static const float *g_box[3] = {0, 0, 0};
+void ok_set_box_sums(const float *bxx, const float *byy, const float *bxy) {
+  g_box[0] = bxx; g_box[1] = byy; g_box[2] = bxy;
+}
+/* window sums of gx*gx, gy*gy, gx*gy over (2hw+1) x (2hh+1): each row of the window summed left to
+ * right, then the row sums top to bottom; windows that leave the image are not candidates (0) */
+void ok_box_products(const float *gx, const float *gy, int W, int H, int hw, int hh, float *bxx,
+                     float *byy, float *bxy) {
+  int x, y, q, dx, dy;
+  float *out[3];
+  out[0] = bxx; out[1] = byy; out[2] = bxy;
+  for (q = 0; q < 3; q++) {
+    float *rs = (float *)malloc(sizeof(float) * (size_t)W * H);
+    for (y = 0; y < H; y++)
+      for (x = 0; x < W; x++) {
+        float acc = 0.0f;
+        if (x - hw >= 0 && x + hw < W)
+          for (dx = -hw; dx <= hw; dx++) {
+            const float a = gx[(size_t)y * W + x + dx], b = gy[(size_t)y * W + x + dx];
+            const float p = q == 0 ? a * a : (q == 1 ? b * b : a * b);
+            acc = dx == -hw ? p : acc + p;
+          }
+        rs[(size_t)y * W + x] = acc;
+      }
+    for (y = 0; y < H; y++)
+      for (x = 0; x < W; x++) {
+        float acc = 0.0f;
+        if (y - hh >= 0 && y + hh < H && x - hw >= 0 && x + hw < W)
+          for (dy = -hh; dy <= hh; dy++) acc = dy == -hh ? rs[(size_t)(y + dy) * W + x] : acc + rs[(size_t)(y + dy) * W + x];
+        out[q][(size_t)y * W + x] = acc;
+      }
+    free(rs);
+  }
+}
+
 static int score_at(const float *sxx, const float *syy, const float *sxy, int W1, int x, int y,
                     int hw, int hh, int min_eig, int round2) {
   const size_t r0 = (size_t)(y - hh) * W1, r1 = (size_t)(y + hh + 1) * W1;
   const int x1 = x - hw, x2 = x + hw + 1;
-  float gxy = sxy[r0 + x1] + sxy[r1 + x2] - sxy[r1 + x1] - sxy[r0 + x2];
-  float gxx = sxx[r0 + x1] + sxx[r1 + x2] - sxx[r1 + x1] - sxx[r0 + x2];
-  float gyy = syy[r0 + x1] + syy[r1 + x2] - syy[r1 + x1] - syy[r0 + x2];
+  float gxy, gxx, gyy;
+  if (g_box[0]) { /* direct sums: H x W planes, row length W1 - 1 */
+    const size_t i = (size_t)y * (W1 - 1) + x;
+    gxx = g_box[0][i]; gyy = g_box[1][i]; gxy = g_box[2][i];
+  } else {
+    gxy = sxy[r0 + x1] + sxy[r1 + x2] - sxy[r1 + x1] - sxy[r0 + x2];
+    gxx = sxx[r0 + x1] + sxx[r1 + x2] - sxx[r1 + x1] - sxx[r0 + x2];
+    gyy = syy[r0 + x1] + syy[r1 + x2] - syy[r1 + x1] - syy[r0 + x2];
+  }
   float v = min_eigenvalue(gxx, gxy, gyy);
   int iv;
   if (round2) {

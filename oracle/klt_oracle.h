@@ -107,6 +107,13 @@ int ok_select_features(ok_params *p, int mode, int variant, const float *sumxx,
                        const float *sumyy, const float *sumxy, int W, int H, int *nFeatures,
                        int capacity, float *x, float *y, int *val, int gridW, int gridH);
 
+/* SURVEY section 7's selector fast path (no counterpart in the reference): window sums formed
+ * directly.  ok_box_products: H x W planes of window sums in a defined order; ok_set_box_sums:
+ * while set (non-NULL), ok_select_features scores from these planes and ignores its sum images. */
+void ok_box_products(const float *gx, const float *gy, int W, int H, int hw, int hh, float *bxx,
+                     float *byy, float *bxy);
+void ok_set_box_sums(const float *bxx, const float *byy, const float *bxy);
+
 void ok_set_threads(int n);
 int ok_get_threads(void);
 

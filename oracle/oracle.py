@@ -250,6 +250,29 @@ def select_features(p, mode, variant, sumxx, sumyy, sumxy, nFeatures, x=None, y=
     return fx[: n.value].copy(), fy[: n.value].copy(), fv[: n.value].copy()
 
 
+def box_products(gx, gy, hw, hh):
+    """H x W planes of window sums of gx*gx, gy*gy, gx*gy (SURVEY section 7 fast path)."""
+    gx = np.ascontiguousarray(gx, np.float32)
+    gy = np.ascontiguousarray(gy, np.float32)
+    H, W = gx.shape
+    b = [np.zeros((H, W), np.float32) for _ in range(3)]
+    lib().ok_box_products(_fp(gx), _fp(gy), W, H, int(hw), int(hh), _fp(b[0]), _fp(b[1]), _fp(b[2]))
+    return b
+
+
+def select_features_direct(p, mode, variant, gx, gy, nFeatures, **kw):
+    """select_features with the candidate scores formed from direct window sums of the level's
+    gradient planes instead of integral images."""
+    H, W = gx.shape
+    b = box_products(gx, gy, p.window_width // 2, p.window_height // 2)
+    dummy = np.zeros((H + 1, W + 1), np.float32)
+    lib().ok_set_box_sums(_fp(b[0]), _fp(b[1]), _fp(b[2]))
+    try:
+        return select_features(p, mode, variant, dummy, dummy, dummy, nFeatures, **kw)
+    finally:
+        lib().ok_set_box_sums(None, None, None)
+
+
 def seed_from_level(p, pyr, level, nFeatures):
     """Keyframe seeding (System.cpp:407-420,672-689: keypoints of the coarsest level x mScaleFactor,
     val = KLT_TRACKED) with the Shi-Tomasi selector in place of ORB's FAST detector, as

@@ -267,3 +267,69 @@ def test_uniform_round_kernels_agree(klt, ok, gpu_ctx, impl, iters, case, grid):
     _same_lists(got, ref)
     if case == "big_scores":
         assert (ref[2] >= (1 << 26)).any()
+
+
+@pytest.mark.parametrize("variant,window,mindist", [("PLAIN", 7, 10), ("UNIFORM", 7, 10), ("PLAIN", 21, 6),
+                                                     ("UNIFORM", 11, 4), ("PLAIN", 3, 1)])
+def test_select_scores_from_direct_window_sums(klt, ok, gpu_ctx, variant, window, mindist):
+    """gklt_ctx_set_select_scores(1), SURVEY section 7's fast path: no integral images, the window
+    sums of gx^2, gy^2, gx gy formed directly.  Identical lists to the oracle's direct form (same
+    summation order), and nearly the selection of the integral-image path (set overlap: the scores
+    differ in the last bits only, which reorders near-ties)."""
+    H, W, n = 270, 480, 400
+    img = _frame(H, W)
+    kw = dict(window=window, levels=2, mindist=mindist, min_eigenvalue=60, border=max(12, window))
+    gp, op = klt.make_params(**kw), ok.make_params(**kw)
+    gpu_ctx.set_params(gp)
+    gv, ov = getattr(klt, "VARIANT_" + variant), getattr(ok, "VARIANT_" + variant)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    fl = klt.FeatureList(gpu_ctx, 100 * n)
+    try:
+        pyr.build(img)
+        gx, gy = pyr.plane(0, 1), pyr.plane(0, 2)
+        lists = []
+        for mode in (1, 0):
+            gpu_ctx.set_select_scores(mode)
+            fl.upload(np.zeros(n, np.float32), np.zeros(n, np.float32), np.full(n, -1, np.int32))
+            klt.select_from_pyramid(gpu_ctx, pyr, klt.SELECT_ALL, gv, fl, grid=(32, 32))
+            lists.append(fl.download())
+    finally:
+        gpu_ctx.set_select_scores(0)
+        fl.close(); pyr.close()
+    direct, integral = lists
+    ref = ok.select_features_direct(op, ok.SELECT_ALL, ov, gx, gy, n, grid=(32, 32), capacity=100 * n)
+    _same_lists(direct, ref)
+    ref_i = ok.select_features(op, ok.SELECT_ALL, ov, *ok.integral_products(gx, gy), n, grid=(32, 32), capacity=100 * n)
+    _same_lists(integral, ref_i)
+    a = {(x, y) for x, y, v in zip(*direct) if v > 0}
+    b = {(x, y) for x, y, v in zip(*integral) if v > 0}
+    assert len(a) > 20 and len(a & b) / len(a | b) > 0.9, (len(a), len(b), len(a & b))
+
+
+def test_seed_from_level_with_direct_scores(klt, ok, gpu_ctx):
+    H, W, n = 270, 480, 150
+    img = _frame(H, W)
+    kw = dict(window=7, levels=3, mindist=6, min_eigenvalue=30)
+    gp, op = klt.make_params(**kw), ok.make_params(**kw)
+    gpu_ctx.set_params(gp)
+    pyr = klt.Pyramid(gpu_ctx, W, H)
+    fl = klt.FeatureList(gpu_ctx, 100 * n)
+    try:
+        pyr.build(img)
+        planes = pyr.planes()
+        gpu_ctx.set_select_scores(1)
+        klt.seed_from_level(gpu_ctx, pyr, 2, fl, n)
+        got = fl.download()
+    finally:
+        gpu_ctx.set_select_scores(0)
+        fl.close(); pyr.close()
+    q = op.copy()
+    q.borderx = (op.borderx + 3) // 4
+    q.bordery = (op.bordery + 3) // 4
+    x, y, v = ok.select_features_direct(q, ok.SELECT_ALL, ok.VARIANT_PLAIN, planes[7], planes[8], n)
+    found = v >= 0
+    x = np.where(found, x * np.float32(4), x).astype(np.float32)
+    y = np.where(found, y * np.float32(4), y).astype(np.float32)
+    v = np.where(found, 0, v).astype(np.int32)
+    _same_lists(got, (x, y, v))
+    assert found.sum() > 20
