@@ -845,14 +845,17 @@ def main(argv=None):
         import torch.distributed as dist  # after libgklt.so: see the module docstring
 
         # gloo announces its connections on the C-level stdout ("[Gloo] Rank 0 is connected to ..."),
-        # which would precede rank 0's ONE JSON line: send whatever the rendezvous prints to stderr
+        # which would precede rank 0's ONE JSON line: fd 1 points at stderr while the group is set up.
+        # (No collective here: a torch collective before the library's first HIP call leaves
+        # hipGetDeviceCount without devices -- two HIP runtimes in the process, see the module docstring.)
+        import ctypes
         sys.stdout.flush()
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
             dist.init_process_group("gloo")
-            dist.barrier()
         finally:
+            ctypes.CDLL(None).fflush(None)  # the notice may sit in libc's stdout buffer
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
