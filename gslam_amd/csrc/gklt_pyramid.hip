@@ -279,6 +279,33 @@ __device__ __forceinline__ float corr_win(const float (&v)[N], int c, const Taps
   return acc;
 }
 
+// The same expression on two columns at once (x = one column, y = its neighbour): every operation
+// is one v_pk_*_f32, each half rounded exactly as the scalar form rounds it.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int R, int N>
+__device__ __forceinline__ v2f corr_win2(const v2f (&v)[N], int c, const Taps &t) {
+  v2f acc = v2f{t.k[0], t.k[0]} * v[c];
+#pragma unroll
+  for (int j = 1; j <= R; ++j) acc = acc + v2f{t.k[j], t.k[j]} * (v[c + j] + v[c - j]);
+  return acc;
+}
+// Both gradient column filters of one pixel at once: v = (rows filtered with G', rows filtered
+// with G); x = symmetric taps g on v.x (gx), y = antisymmetric taps d on v.y (gy); K[j] = (g[j], d[j]).
+// The y half starts from 0.0f and its pair differences come from the negate-source modifier of the
+// packed add (a + (-b) is a - b bit for bit): the bits of corr_win<R, -1>.
+__device__ __forceinline__ v2f pk_add_sub(v2f a, v2f b) {  // (a.x + b.x, a.y - b.y)
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int R, int N>
+__device__ __forceinline__ v2f corr_win_gxgy(const v2f (&v)[N], int c, const v2f (&K)[R + 1]) {
+  v2f acc = v2f{K[0].x * v[c].x, 0.0f};
+#pragma unroll
+  for (int j = 1; j <= R; ++j) acc = acc + K[j] * pk_add_sub(v[c + j], v[c - j]);
+  return acc;
+}
+
 #ifdef GKLT_PYR_FMA
 // taps k[1 .. R + 1] of the polyphase pyramid filter (see level_tile), k[0] unused
 template <int R>
@@ -487,7 +514,7 @@ struct LevelGeom {
   static constexpr int NGA = (OA + 3 + 2 * R0) / 4 + 1;
   static constexpr int OI = HIP - HI;             // first needed float of an I row window
   static constexpr int NGI = (OI + 3 + 2 * HI) / 4 + 1;
-  static constexpr int STRIPS = LNT / AW;          // column pass of level 0: strips per column
+  static constexpr int STRIPS = LNT / (AW / 2);    // column pass of level 0: strips per column pair
   static constexpr int SR = (IHh + STRIPS - 1) / STRIPS;
   static_assert(SW <= 128 && AW % 4 == 0, "two lane chunks per staged row");
   static_assert(4 * NGA - 4 <= 2 * R0P && 60 + 4 * NGI <= AW, "row windows stay inside a row");
@@ -565,12 +592,18 @@ __device__ __forceinline__ void stage_region_u8x4(const uint8_t *__restrict__ sr
   }
 }
 
+// NG float4 groups of an LDS row into registers, each as ONE ds_read_b128.  The loads are volatile on
+// purpose: a window uses only part of its first and last group, and the compiler otherwise narrows
+// those (and, with them, the rest) to ds_read2_b32 / ds_read_b64 -- whose lanes, 16 bytes apart, fall
+// on a quarter of the banks: measured 24 LDS cycles per group read instead of 4, a third of the
+// level-0 kernel's LDS time (profiles/r03_level0_lds_*.txt).
 template <int NG>
 __device__ __forceinline__ void load_groups(const float *p, float (&v)[4 * NG]) {
-  const float4 *q4 = reinterpret_cast<const float4 *>(p);
+  typedef const volatile v4f __attribute__((address_space(3))) * lds_v4f_ptr;  // LDS, not a flat address
+  lds_v4f_ptr q4 = (lds_v4f_ptr)p;
 #pragma unroll
   for (int q = 0; q < NG; ++q) {
-    const float4 f = q4[q];
+    const v4f f = q4[q];
     v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
   }
 }
@@ -640,17 +673,19 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
       *reinterpret_cast<float4 *>(A + ty * G::AW + 4 * gq) = o;
     }
     __syncthreads();
-    if ((int)threadIdx.x < G::STRIPS * G::AW) {
-      const int strip = threadIdx.x / G::AW, col = threadIdx.x - strip * G::AW;
-      float v[G::SR + 2 * R0];
+    if ((int)threadIdx.x < G::STRIPS * (G::AW / 2)) {
+      // a lane owns a PAIR of adjacent columns (one ds_read_b64 per row), so that every add and
+      // multiply of the pass is one packed-fp32 instruction on the pair
+      const int strip = threadIdx.x / (G::AW / 2), cp = threadIdx.x - strip * (G::AW / 2);
+      const v2f *A2 = reinterpret_cast<const v2f *>(A) + cp;
+      v2f v[G::SR + 2 * R0];
 #pragma unroll
-      for (int i = 0; i < G::SR + 2 * R0; ++i)
-        v[i] = A[min(strip * G::SR + i, G::SH - 1) * G::AW + col];
+      for (int i = 0; i < G::SR + 2 * R0; ++i) v[i] = A2[min(strip * G::SR + i, G::SH - 1) * (G::AW / 2)];
 #pragma unroll
       for (int j = 0; j < G::SR; ++j) {
         const int rr = strip * G::SR + j;
-        const float o = corr_win<R0, +1>(v, R0 + j, s0);
-        if (rr < G::IHh) I[rr * G::AW + col] = o;
+        const v2f o = corr_win2<R0>(v, R0 + j, s0);
+        if (rr < G::IHh) reinterpret_cast<v2f *>(I)[rr * (G::AW / 2) + cp] = o;
       }
     }
     __syncthreads();
@@ -659,12 +694,18 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
     __syncthreads();
   }
 
-  float *rowd = scratch;            // GH x TW  : rows filtered with G'
-  float *rowg = rowd + GH * TW;     // GH x TW  : rows filtered with G
-  float *rowp = rowg + GH * TW;     // IHh x TW : rows filtered with the pyramid kernel (DOWN)
+  // rows filtered with G' (even rows of rowdg) and with G (odd rows), interleaved row by row: the
+  // column pass reads the two values of a pixel with one ds_read2st64_b32 into one register pair
+  float *rowdg = scratch;               // 2 GH x TW
+  float *rowp = rowdg + 2 * GH * TW;    // IHh x TW : rows filtered with the pyramid kernel (DOWN)
 #pragma unroll
   for (int task = threadIdx.x; task < G::IHh * (TW / 4); task += LNT) {
-    const int ty = task >> 4, gq = task & 15;
+    // 32 consecutive tasks = two rows of 16 float4 groups.  ds_read_b128 serves a wave in the lane
+    // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with the row chosen by the parity of
+    // the lane's quad index each hardware group reads 16 contiguous groups of ONE row (all 64 banks
+    // once, whatever the row stride), and the 8-lane groups of the ds_write_b128 stay conflict-free
+    // (tools/lds_model.py); `task >> 4` as the row costs every read a second LDS cycle.
+    const int ty = 2 * (task >> 5) + (__builtin_popcount((task >> 2) & 7) & 1), gq = task & 15;
     float v[4 * G::NGI];
     load_groups<G::NGI>(I + ty * G::AW + 4 * gq, v);
     constexpr int C = G::OI + HI;
@@ -691,34 +732,45 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
       od.y = corr_win<RG, -1>(v, C + 1, d); og.y = corr_win<RG, +1>(v, C + 1, g);
       od.z = corr_win<RG, -1>(v, C + 2, d); og.z = corr_win<RG, +1>(v, C + 2, g);
       od.w = corr_win<RG, -1>(v, C + 3, d); og.w = corr_win<RG, +1>(v, C + 3, g);
-      *reinterpret_cast<float4 *>(rowd + tg * TW + 4 * gq) = od;
-      *reinterpret_cast<float4 *>(rowg + tg * TW + 4 * gq) = og;
+      *reinterpret_cast<float4 *>(rowdg + 2 * tg * TW + 4 * gq) = od;
+      *reinterpret_cast<float4 *>(rowdg + (2 * tg + 1) * TW + 4 * gq) = og;
     }
   }
   __syncthreads();
 
   {  // gradient column pass -> texels
-    float vd[RPW + 2 * RG], vg[RPW + 2 * RG];
+    // (G'-filtered, G-filtered) of a row as one register pair: both column filters run as packed fp32
+    v2f vdg[RPW + 2 * RG], K[RG + 1];
 #pragma unroll
-    for (int i = 0; i < RPW + 2 * RG; ++i) {
-      vd[i] = rowd[(RPW * wave + i) * TW + lane];
-      vg[i] = rowg[(RPW * wave + i) * TW + lane];
+    for (int j = 0; j <= RG; ++j) {
+      float kg = g.k[j], kd = d.k[j];
+      asm("" : "+v"(kg), "+v"(kd));  // taps in VGPRs: the pair is then a register sequence
+      K[j] = v2f{kg, kd};
     }
-    const int x = x0 + lane;
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-      const int y = y0 + RPW * wave + j;
-      const float gx = corr_win<RG, +1>(vd, RG + j, g);
-      const float gy = corr_win<RG, -1>(vg, RG + j, d);
-      const float ic = I[(RPW * wave + j + HI) * G::AW + G::HIP + lane];
-      if (x < w && y < h) {
-        // streaming store: the texels are next read by a tracker launch at least one build
-        // later, and must not evict the window footprints a concurrent tracker gathers from L2
-        Texel *const t = tex + (size_t)y * w + x;  // the three stores merge into one dwordx3
-        __builtin_nontemporal_store(ic, &t->x);
-        __builtin_nontemporal_store(gx, &t->y);
-        __builtin_nontemporal_store(gy, &t->z);
-        if (img_out) img_out[(size_t)y * w + x] = ic;
+    for (int i = 0; i < RPW + 2 * RG; ++i)
+      vdg[i] = v2f{rowdg[2 * (RPW * wave + i) * TW + lane], rowdg[(2 * (RPW * wave + i) + 1) * TW + lane]};
+    const int x = x0 + lane;
+    // row pointers are wave-uniform (SGPRs); the lane's part of the address is one 32-bit offset
+    const unsigned xoff = (unsigned)lane * (unsigned)sizeof(Texel);
+    if (x < w) {
+#pragma unroll
+      for (int j = 0; j < RPW; ++j) {
+        const int y = y0 + RPW * wave + j;
+        const v2f gxy = corr_win_gxgy<RG>(vdg, RG + j, K);
+        const float ic = I[(RPW * wave + j + HI) * G::AW + G::HIP + lane];
+        if (y < h) {
+          // streaming store: the texels are next read by a tracker launch at least one build
+          // later, and must not evict the window footprints a concurrent tracker gathers from L2
+          char *trow = reinterpret_cast<char *>(tex + (size_t)y * w + x0);
+          asm("" : "+s"(trow));  // keeps the row pointer in SGPRs: store address = SGPR base + lane offset
+          typedef float __attribute__((address_space(1))) * global_float_ptr;  // global, not a flat address
+          global_float_ptr t = (global_float_ptr)(trow + xoff);  // the three stores merge into one dwordx3
+          __builtin_nontemporal_store(ic, t);
+          __builtin_nontemporal_store(gxy.x, t + 1);
+          __builtin_nontemporal_store(gxy.y, t + 2);
+          if (img_out) img_out[(size_t)y * w + x] = ic;
+        }
       }
     }
   }
@@ -743,19 +795,23 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
   }
 #else
   if constexpr (DOWN) {  // pyramid column pass -> 2x2 mean -> next level
-    float v[RPW + 2 * RP], o[RPW];
+    // a lane owns a pair of adjacent columns and half of its wave's rows: packed fp32 throughout,
+    // and the four pixels of a 2 x 2 block are in one lane (no cross-lane traffic for the mean)
+    constexpr int RL = RPW / 2;  // rows per lane
+    static_assert(RL % 2 == 0, "whole 2 x 2 blocks per lane");
+    const int xq = lane & 31, half = lane >> 5;
+    const v2f *P2 = reinterpret_cast<const v2f *>(rowp) + (RPW * wave + RL * half + HI - RP) * (TW / 2) + xq;
+    v2f v[RL + 2 * RP], o[RL];
 #pragma unroll
-    for (int i = 0; i < RPW + 2 * RP; ++i) v[i] = rowp[(RPW * wave + i + HI - RP) * TW + lane];
+    for (int i = 0; i < RL + 2 * RP; ++i) v[i] = P2[i * (TW / 2)];
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) o[j] = corr_win<RP, +1>(v, RP + j, pyr);
-    const int x = x0 / 2 + (lane >> 1);
+    for (int j = 0; j < RL; ++j) o[j] = corr_win2<RP>(v, RP + j, pyr);
+    const int x = x0 / 2 + xq;
 #pragma unroll
-    for (int jj = 0; jj < RPW / 2; ++jj) {
-      const float a = o[2 * jj], c = o[2 * jj + 1];
-      const float b = __shfl_xor(a, 1), e = __shfl_xor(c, 1);
-      const float m = GKLT_MEAN2X2(a, b, c, e);
-      const int y = y0 / 2 + RPW / 2 * wave + jj;
-      if (!(lane & 1) && x < w2 && y < h2) {
+    for (int jj = 0; jj < RL / 2; ++jj) {
+      const float m = GKLT_MEAN2X2(o[2 * jj].x, o[2 * jj].y, o[2 * jj + 1].x, o[2 * jj + 1].y);
+      const int y = y0 / 2 + RPW / 2 * wave + RL / 2 * half + jj;
+      if (x < w2 && y < h2) {
         if constexpr (THROUGH)
           __hip_atomic_store(reinterpret_cast<unsigned *>(down + (size_t)y * w2 + x), __float_as_uint(m),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
