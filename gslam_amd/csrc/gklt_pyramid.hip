@@ -282,6 +282,7 @@ __device__ __forceinline__ float corr_win(const float (&v)[N], int c, const Taps
 // The same expression on two columns at once (x = one column, y = its neighbour): every operation
 // is one v_pk_*_f32, each half rounded exactly as the scalar form rounds it.
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 template <int R, int N>
 __device__ __forceinline__ v2f corr_win2(const v2f (&v)[N], int c, const Taps &t) {
   v2f acc = v2f{t.k[0], t.k[0]} * v[c];
@@ -349,17 +350,37 @@ __device__ __forceinline__ void stage_fast(const SrcT *__restrict__ src, int str
   }
 }
 
+// NG float4 groups of an LDS row into registers, each as ONE ds_read_b128.  The loads are volatile on
+// purpose: a window uses only part of its first and last group, and the compiler otherwise narrows
+// those (and, with them, the rest) to ds_read2_b32 / ds_read_b64 -- whose lanes, 16 bytes apart, fall
+// on a quarter of the banks: measured 24 LDS cycles per group read instead of 4, a third of the
+// level-0 kernel's LDS time (profiles/r03_level0_lds_*.txt).
+template <int NG>
+__device__ __forceinline__ void load_groups(const float *p, float (&v)[4 * NG]) {
+  typedef const volatile v4f __attribute__((address_space(3))) * lds_v4f_ptr;  // LDS, not a flat address
+  lds_v4f_ptr q4 = (lds_v4f_ptr)p;
+#pragma unroll
+  for (int q = 0; q < NG; ++q) {
+    const v4f f = q4[q];
+    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+  }
+}
+
+// row of task t of a row pass over rows of 16 float4 groups: 32 consecutive tasks are two rows, and
+// the row is chosen by the parity of the lane's quad index, so that each of ds_read_b128's lane
+// groups ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, +32) reads 16 contiguous groups of ONE row --
+// all 64 banks once, whatever the row stride -- and the 8-lane groups of ds_write_b128 stay
+// conflict-free (tools/lds_model.py).  Needs an even number of rows.
+__device__ __forceinline__ int row_of_task16(int task) {
+  return 2 * (task >> 5) + (__builtin_popcount((task >> 2) & 7) & 1);
+}
+
 // loads the 4-output window of row task (ty, g) into registers
 template <int R>
 __device__ __forceinline__ void load_window(const float *in, int ty, int g,
                                             float (&v)[4 * FastGeom<R>::NG]) {
   using G = FastGeom<R>;
-  const float4 *p = reinterpret_cast<const float4 *>(in + ty * G::IWP + 4 * g);
-#pragma unroll
-  for (int q = 0; q < G::NG; ++q) {
-    const float4 f = p[q];
-    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-  }
+  load_groups<G::NG>(in + ty * G::IWP + 4 * g, v);
 }
 
 template <typename SrcT, int MODE, int R>
@@ -377,7 +398,7 @@ __global__ __launch_bounds__(NT) void k_smooth_fast(const SrcT *__restrict__ src
   __syncthreads();
 #pragma unroll
   for (int task = threadIdx.x; task < G::ROW_TASKS; task += NT) {
-    const int ty = task >> 4, gq = task & 15;
+    const int ty = row_of_task16(task), gq = task & 15;
     float v[4 * G::NG];
     load_window<R>(in, ty, gq, v);
     float4 o;
@@ -435,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_grad_fast(GradBatch batch, Taps g, Taps 
   __syncthreads();
 #pragma unroll
   for (int task = threadIdx.x; task < G::ROW_TASKS; task += NT) {
-    const int ty = task >> 4, gq = task & 15;
+    const int ty = row_of_task16(task), gq = task & 15;
     float v[4 * G::NG];
     load_window<R>(in, ty, gq, v);
     float4 od, og;
@@ -490,7 +511,6 @@ constexpr size_t fast_grad_lds() {
 // level 0 the halo pixels are smoothed from the reflected u8 window, which gives the same bits
 // as reflecting the smoothed plane because the taps are symmetric and each pair sum
 // (s[+j] + s[-j]) is commutative.  All passes are the register-blocked ones described above.
-typedef float v4f __attribute__((ext_vector_type(4)));
 
 // The fused level kernel works on 64 x 32 tiles with 8 waves (4 output rows per wave): compared
 // with 64 x 16 the halo rows (2 * (HI + R0) = 14 at C2) are shared by twice as many outputs, which
@@ -592,22 +612,6 @@ __device__ __forceinline__ void stage_region_u8x4(const uint8_t *__restrict__ sr
   }
 }
 
-// NG float4 groups of an LDS row into registers, each as ONE ds_read_b128.  The loads are volatile on
-// purpose: a window uses only part of its first and last group, and the compiler otherwise narrows
-// those (and, with them, the rest) to ds_read2_b32 / ds_read_b64 -- whose lanes, 16 bytes apart, fall
-// on a quarter of the banks: measured 24 LDS cycles per group read instead of 4, a third of the
-// level-0 kernel's LDS time (profiles/r03_level0_lds_*.txt).
-template <int NG>
-__device__ __forceinline__ void load_groups(const float *p, float (&v)[4 * NG]) {
-  typedef const volatile v4f __attribute__((address_space(3))) * lds_v4f_ptr;  // LDS, not a flat address
-  lds_v4f_ptr q4 = (lds_v4f_ptr)p;
-#pragma unroll
-  for (int q = 0; q < NG; ++q) {
-    const v4f f = q4[q];
-    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
-  }
-}
-
 // blockIdx.z = frame of the batch (lookahead builds put several frames into one launch)
 struct LevelIO {
   const void *src[GKLT_MAX_LOOKAHEAD];
@@ -700,12 +704,7 @@ __device__ __forceinline__ void level_tile(const SrcT *__restrict__ src, Texel *
   float *rowp = rowdg + 2 * GH * TW;    // IHh x TW : rows filtered with the pyramid kernel (DOWN)
 #pragma unroll
   for (int task = threadIdx.x; task < G::IHh * (TW / 4); task += LNT) {
-    // 32 consecutive tasks = two rows of 16 float4 groups.  ds_read_b128 serves a wave in the lane
-    // groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): with the row chosen by the parity of
-    // the lane's quad index each hardware group reads 16 contiguous groups of ONE row (all 64 banks
-    // once, whatever the row stride), and the 8-lane groups of the ds_write_b128 stay conflict-free
-    // (tools/lds_model.py); `task >> 4` as the row costs every read a second LDS cycle.
-    const int ty = 2 * (task >> 5) + (__builtin_popcount((task >> 2) & 7) & 1), gq = task & 15;
+    const int ty = row_of_task16(task), gq = task & 15;
     float v[4 * G::NGI];
     load_groups<G::NGI>(I + ty * G::AW + 4 * gq, v);
     constexpr int C = G::OI + HI;
