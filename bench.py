@@ -953,6 +953,7 @@ def main(argv=None):
     if B and not a.main_only:
         st.seeds = (np.zeros(0, np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32))
         st.la.upload_features(*st.seeds)  # (the periodic re-seed then uploads the empty list too)
+        ctx.set_coarse_split(0)           # one build stream: no coarse level of the batch before beside level 0
         st.run(2 * B)
         st.sync()
         ctx.profile_enable(True)
@@ -961,6 +962,7 @@ def main(argv=None):
         st.sync()
         alone = {k: ms / cnt * 1e3 for k, (ms, cnt) in ctx.profile_get().items() if cnt}
         ctx.profile_enable(False)
+        ctx.set_coarse_split(1)
 
     if not B:
         fa1 = (tracked, dt, a.steps)

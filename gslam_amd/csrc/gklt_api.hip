@@ -180,6 +180,7 @@ extern "C" int gklt_ctx_create(int device, gklt_ctx **out) {
     GKLT_HIP(hipGetSymbolAddress(&c->noalloc_scratch, HIP_SYMBOL(scratch)));
     GKLT_HIP(hipHostMalloc(reinterpret_cast<void **>(&c->h_chain_err), sizeof(unsigned), hipHostMallocDefault));
     *c->h_chain_err = 0;
+    if (const char *e = std::getenv("GKLT_COARSE_SPLIT")) c->coarse_split = std::atoi(e) ? 1 : 0;  // A/B runs
     if (const char *e = std::getenv("GKLT_CHAIN")) c->chain_levels = std::min(std::max(std::atoi(e), 0), 2);  // A/B runs
     return 0;
   }();
@@ -199,6 +200,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   if (!ctx) return 0;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->s_pyr);
+  if (ctx->s_pyr2) (void)hipStreamSynchronize(ctx->s_pyr2);
   (void)hipStreamSynchronize(ctx->s_trk);
   fold_spans(ctx);
   for (auto e : ctx->free_events) (void)hipEventDestroy(e);
@@ -216,6 +218,7 @@ extern "C" int gklt_ctx_destroy(gklt_ctx *ctx) {
   (void)hipFree(ctx->d_vec);
   (void)hipFree(ctx->d_rot);
   (void)hipStreamDestroy(ctx->s_pyr);
+  if (ctx->s_pyr2) (void)hipStreamDestroy(ctx->s_pyr2);
   (void)hipStreamDestroy(ctx->s_trk);
   delete ctx;
   return 0;
@@ -246,6 +249,7 @@ extern "C" int gklt_sync(gklt_ctx *ctx) {
   if (!ctx) return GKLT_EINVAL;
   if (int rc = use_device(ctx)) return rc;
   GKLT_HIP(hipStreamSynchronize(ctx->s_pyr));
+  if (ctx->s_pyr2) GKLT_HIP(hipStreamSynchronize(ctx->s_pyr2));
   GKLT_HIP(hipStreamSynchronize(ctx->s_trk));
   if (*ctx->h_chain_err) {
     *ctx->h_chain_err = 0;
@@ -477,8 +481,12 @@ int enqueue_build_unfused(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const 
 }
 }  // namespace
 
+// s_coarse / e_level0 (optional, fused builds only): levels 1 .. L-1 go to s_coarse after an event
+// recorded behind level 0 on s -- the caller's next batch can then start its level 0 on s while
+// this batch's coarse levels, which fill the chip less and less, run beside it.
 int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py,
-                              const uint8_t *const *src, int n, int src_stride) {
+                              const uint8_t *const *src, int n, int src_stride,
+                              hipStream_t s_coarse, hipEvent_t e_level0) {
   if (n < 1 || n > GKLT_MAX_LOOKAHEAD) return GKLT_EINVAL;
   const gklt_pyramid *p0 = py[0];
   BuildTaps t;
@@ -493,6 +501,16 @@ int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const 
   if (!fuse) {
     for (int i = 0; i < n; ++i)
       if (int rc = enqueue_build_unfused(ctx, s, py[i], src[i], src_stride, t)) return rc;
+    if (s_coarse && e_level0) {  // the caller takes s_coarse as the stream the build ends on
+      GKLT_HIP(hipEventRecord(e_level0, s));
+      GKLT_HIP(hipStreamWaitEvent(s_coarse, e_level0, 0));
+    }
+    return 0;
+  }
+  if (p0->nlevels == 1 && s_coarse && e_level0) {
+    if (int rc = enqueue_build_batch(ctx, s, py, src, n, src_stride)) return rc;
+    GKLT_HIP(hipEventRecord(e_level0, s));
+    GKLT_HIP(hipStreamWaitEvent(s_coarse, e_level0, 0));
     return 0;
   }
   // single frame, default kernels, every level an exact 2x decimation: levels 1 .. L-1 in one launch
@@ -501,6 +519,11 @@ int gklt::enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const 
   for (int l = 0; chain && l + 1 < p0->nlevels; ++l)
     chain = p0->lv[l].w == 2 * p0->lv[l + 1].w && p0->lv[l].h == 2 * p0->lv[l + 1].h;
   for (int l = 0; l < p0->nlevels; ++l) {
+    if (l == 1 && s_coarse && e_level0) {
+      GKLT_HIP(hipEventRecord(e_level0, s));
+      GKLT_HIP(hipStreamWaitEvent(s_coarse, e_level0, 0));
+      s = s_coarse;
+    }
     if (chain && l == 1) return launch_level_chain(ctx, s, py, n, t.pyr, t.gradg, t.gradd);
     const Level &a = p0->lv[l];
     const bool last = l + 1 == p0->nlevels;
@@ -992,6 +1015,22 @@ extern "C" int gklt_device_synchronize(gklt_ctx *ctx) {
 extern "C" int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl) {
   if (!ctx || impl < 0 || impl > 3) return GKLT_EINVAL;
   ctx->track_impl = impl;
+  return 0;
+}
+
+// Lookahead pipeline: 1 = the coarse levels of a batch run on a second build stream, so that level 0
+// of the next batch overlaps them; 0 = one build stream.
+extern "C" int gklt_ctx_set_coarse_split(gklt_ctx *ctx, int on) {
+  if (!ctx) return GKLT_EINVAL;
+  ctx->coarse_split = on ? 1 : 0;
+  return 0;
+}
+
+// the second build stream, created on first use (a process has few hardware queues: contexts that
+// never split their builds do not take one)
+int gklt::coarse_stream(gklt_ctx *ctx, hipStream_t *out) {
+  if (!ctx->s_pyr2) GKLT_HIP(hipStreamCreateWithFlags(&ctx->s_pyr2, hipStreamNonBlocking));
+  *out = ctx->s_pyr2;
   return 0;
 }
 

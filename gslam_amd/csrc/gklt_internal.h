@@ -82,6 +82,8 @@ struct gklt_ctx {
   gklt::RansacScratch *ransac = nullptr;
   gklt_params prm{};
   hipStream_t s_pyr = nullptr;  // pyramid builds
+  hipStream_t s_pyr2 = nullptr; // coarse levels of batched builds (lookahead pipeline), created on first use
+  int coarse_split = 1;         // gklt_ctx_set_coarse_split
   hipStream_t s_trk = nullptr;  // tracker, feature list copies
   // staging for host frames / host feature lists (grown on demand)
   uint8_t *d_frame = nullptr;
@@ -240,6 +242,9 @@ int enqueue_build(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *py, const uint8_t 
 // the same for n same-sized pyramids (n <= GKLT_MAX_LOOKAHEAD): fused levels take one launch per
 // level for the whole batch
 int enqueue_build_batch(gklt_ctx *ctx, hipStream_t s, gklt_pyramid *const *py,
-                        const uint8_t *const *src, int n, int src_stride);
+                        const uint8_t *const *src, int n, int src_stride,
+                        hipStream_t s_coarse = nullptr, hipEvent_t e_level0 = nullptr);
+
+int coarse_stream(gklt_ctx *ctx, hipStream_t *out);
 
 }  // namespace gklt

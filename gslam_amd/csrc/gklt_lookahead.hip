@@ -12,7 +12,9 @@
 //
 // Streams (the context's s_pyr / s_trk): P builds, T tracks.  submit(k) enqueues  P: wait(T done k-1); build batch k
 //                                                   T: wait(P done k-1); track batch k-1
-// so build(k) overlaps track(k-1).  The ring holds 2*max_batch+1 pyramids: batch k overwrites the
+// so build(k) overlaps track(k-1).  With gklt_ctx_set_coarse_split the build is level 0 on P and the
+// coarse levels on a second build stream P2 behind an event: level 0 of batch k+1 follows level 0 of
+// batch k on P and overlaps the coarse levels of batch k; "P done" is then recorded on P2.  The ring holds 2*max_batch+1 pyramids: batch k overwrites the
 // slots of frames that the tracker launch of submit(k-1) was the last to read.
 #include <vector>
 
@@ -26,6 +28,9 @@ struct gklt_lookahead {
   std::vector<gklt_pyramid *> ring;
   gklt_flist *fl = nullptr;
   hipStream_t sp = nullptr, st = nullptr;
+  hipStream_t sp2 = nullptr;      // coarse levels (gklt_ctx_set_coarse_split), the context's s_pyr2
+  hipEvent_t e_level0 = nullptr;  // level 0 of the batch is enqueued up to here on sp
+  hipStream_t s_built = nullptr;  // stream the last build ends on (sp or sp2)
   hipEvent_t e_built = nullptr, e_tracked = nullptr;
   bool has_built = false, has_tracked = false;
   // Host frames: staged H2D on a copy stream of their own, two sets of staging buffers taking
@@ -87,6 +92,7 @@ extern "C" int gklt_lookahead_sync(gklt_lookahead *p) {
   GKLT_HIP(hipSetDevice(p->ctx->device));
   if (p->sc) GKLT_HIP(hipStreamSynchronize(p->sc));
   if (p->sp) GKLT_HIP(hipStreamSynchronize(p->sp));
+  if (p->sp2) GKLT_HIP(hipStreamSynchronize(p->sp2));
   if (p->st) GKLT_HIP(hipStreamSynchronize(p->st));
   return 0;
 }
@@ -95,7 +101,9 @@ extern "C" int gklt_lookahead_destroy(gklt_lookahead *p) {
   if (!p) return 0;
   (void)hipSetDevice(p->ctx->device);
   if (p->sp) (void)hipStreamSynchronize(p->sp);
+  if (p->sp2) (void)hipStreamSynchronize(p->sp2);
   if (p->st) (void)hipStreamSynchronize(p->st);
+  if (p->e_level0) (void)hipEventDestroy(p->e_level0);
   for (auto *py : p->ring) gklt_pyramid_destroy(py);
   gklt_flist_destroy(p->fl);
   if (p->sc) (void)hipStreamSynchronize(p->sc);
@@ -151,7 +159,29 @@ static int enqueue_batch_build(gklt_lookahead *p, long first, const uint8_t *con
     py[i] = slot(p, first + i);
     if (on_device) src[i] = frames[i];
   }
-  if (int rc = enqueue_build_batch(p->ctx, p->sp, py, src, n, src_stride)) return rc;
+  // Coarse levels on a second stream when the context asks for it: level 0 of the NEXT batch, which
+  // follows on sp, then runs beside them instead of behind them (they are short launches that fill
+  // the chip less and less: 4080, 1088 and 320 workgroups per 16 C2 frames).
+  p->s_built = p->sp;
+  // (not with host frames: their copy stream is the process's fourth stream already, a fifth shares a
+  // hardware queue with one of the others -- measured: PCIe-inclusive lookahead 69 -> 58 M at C2)
+  if (p->ctx->coarse_split && n > 1 && on_device) {
+    if (!p->sp2) {
+      if (int rc = coarse_stream(p->ctx, &p->sp2)) return rc;
+      if (hipEventCreateWithFlags(&p->e_level0, hipEventDisableTiming) != hipSuccess) {
+        set_error("lookahead event could not be created");
+        return GKLT_EHIP;
+      }
+    }
+    // (the coarse levels overwrite planes the tracker launch before last read: they start behind
+    // e_level0, i.e. behind level 0 on sp, which the caller made wait for that launch)
+    if (int rc = enqueue_build_batch(p->ctx, p->sp, py, src, n, src_stride, p->sp2, p->e_level0)) return rc;
+    p->s_built = p->sp2;
+  } else {
+    // (a one-stream batch after split ones touches other ring slots than their coarse levels, and
+    // the tracker reaches it in stream order behind the launches that waited for those)
+    if (int rc = enqueue_build_batch(p->ctx, p->sp, py, src, n, src_stride)) return rc;
+  }
   if (!on_device) {
     GKLT_HIP(hipEventRecord(p->e_stage_free[set], p->sp));
     p->stage_used[set] = true;
@@ -233,7 +263,7 @@ extern "C" int gklt_lookahead_submit(gklt_lookahead *p, const uint8_t *const *fr
   // pace of the batch, starts late.
   if (int rc = enqueue_pending_track(p)) return rc;
   if (int rc = enqueue_batch_build(p, p->built + 1, frames, n, stride, on_device)) return rc;
-  GKLT_HIP(hipEventRecord(p->e_built, p->sp));
+  GKLT_HIP(hipEventRecord(p->e_built, p->s_built));
   p->has_built = true;
   for (int i = 0; i < n; ++i) {
     p->pending_mirror[i] = nullptr;

@@ -1205,8 +1205,13 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
     // that takes more of the chip's wave slots for the length of a whole batch starves the pyramid
     // build it overlaps with (C3, 16000 features, lookahead 16: cap 4096 -> 117 M, 8192 -> 112 M,
     // uncapped -> 106 M feature-frames/s).  Single-frame launches are short and latency matters:
-    // one wavefront per feature.
-    const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? 4096 : n));
+    // one wavefront per feature.  Round 3, after the level kernels got faster: windows that do
+    // not fit the footprint-in-registers kernel (more than 64 footprint texels: 11 x 11 and up) do
+    // best at 6 wavefronts per SIMD (C3: 4096 -> 144.7 M, 6144 -> 151.8 M, 8192 -> 145.3 M), the
+    // 7 x 7 kernel stays at 4 (C2 unchanged up to 6144; 16 streams 196 M at 4096, 177 M at 6144):
+    // tools/sweep_waves.sh.
+    const int cap = g.frm ? 4096 : 6144;
+    const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? cap : n));
     TrackFrames F{};
     F.nframes = nframes;
     for (int j = 0; j <= nframes; ++j)

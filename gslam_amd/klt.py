@@ -183,6 +183,9 @@ class Context:
     def set_chain(self, on):
         _check(lib().gklt_ctx_set_chain(self.h, int(on)))
 
+    def set_coarse_split(self, on):
+        _check(lib().gklt_ctx_set_coarse_split(self.h, int(on)))
+
     def set_pyramid_impl(self, impl):
         """0 = fused level kernels when the radii allow (default), 1 = separate kernels."""
         _check(lib().gklt_ctx_set_pyramid_impl(self.h, int(impl)))

@@ -449,9 +449,10 @@ int gklt_device_mem_info(gklt_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
  * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
 /* Wavefronts per wave-per-feature tracker launch; each takes features w, w + waves, ...  The
- * default (0) is one wavefront per feature for single-frame launches and a cap of 4096 wavefronts
- * (4 per SIMD) for the multi-frame launches of the lookahead pipeline, so that the
- * pyramid build it overlaps with always finds room.  Results do not depend on it. */
+ * default (0) is one wavefront per feature for single-frame launches and, for the multi-frame
+ * launches of the lookahead pipeline, a cap of 4096 wavefronts (4 per SIMD; 6144 for windows
+ * of more than 64 footprint texels, e.g. 11 x 11), so that the pyramid build it overlaps with always finds room.
+ * Results do not depend on it. */
 int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
 /* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level; 64 x 32
  * tiles) when the kernel radii are the reference's defaults, separate kernels otherwise
@@ -468,6 +469,11 @@ int gklt_ctx_set_pyramid_impl(gklt_ctx *ctx, int impl);
  * (0: one launch per level; 2: batched builds take the chained launch too -- measured slower).
  * Same results. */
 int gklt_ctx_set_chain(gklt_ctx *ctx, int on);
+/* Lookahead pipeline (gklt_lookahead_*): 1 = the coarse levels of a batch run on a second build
+ * stream behind level 0, so that level 0 of the next batch overlaps them (they are short launches
+ * that fill the chip less and less); 0 = the whole build on one stream.  Same results; no
+ * counterpart in the reference (its preload thread builds one pyramid at a time, System.h:30-56). */
+int gklt_ctx_set_coarse_split(gklt_ctx *ctx, int on);
 /* Suppression rounds of the selectors (plain / ...2, and the uncapped phase of the Uniform one):
  * 0 (default) = rounds on box tops -- one candidate per (r+1) x (r+1) box is examined instead of
  * every pixel -- for radii 4..~45, dense rounds on 32-bit keys otherwise; 1 = dense rounds on

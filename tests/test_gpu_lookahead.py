@@ -36,14 +36,19 @@ def _same(out, ref, what):
     assert (out[1].view(np.uint32) == ry.view(np.uint32)).all(), what
 
 
-@pytest.mark.parametrize("batches,device_frames,pinned", [
-    ([1, 1, 1, 1, 1, 1, 1, 1], False, True),   # degenerate: frame at a time
-    ([3, 3, 2], False, True),                  # ragged last batch
-    ([8], True, True),                         # one full batch, frames resident in HBM
-    ([4, 4], True, False),                     # pageable host_out: copy path
-    ([2, 5, 1], False, True),
+@pytest.mark.parametrize("batches,device_frames,pinned,split", [
+    ([1, 1, 1, 1, 1, 1, 1, 1], False, True, 0),   # degenerate: frame at a time
+    ([3, 3, 2], False, True, 0),                  # ragged last batch
+    ([8], True, True, 0),                         # one full batch, frames resident in HBM
+    ([4, 4], True, False, 0),                     # pageable host_out: copy path
+    ([2, 5, 1], False, True, 0),
+    # coarse levels on the second build stream (gklt_ctx_set_coarse_split): more batches than the
+    # ring holds, one-frame batches (built on one stream) between split ones, host and device frames
+    ([3, 3, 3, 3, 3, 3, 2], True, True, 1),
+    ([2, 1, 4, 1, 1, 4, 3], False, True, 1),
+    ([4, 4, 4, 4], True, False, 1),
 ])
-def test_lookahead_matches_oracle(klt, ok, gpu_ctx, batches, device_frames, pinned):
+def test_lookahead_matches_oracle(klt, ok, gpu_ctx, batches, device_frames, pinned, split):
     H, W, n = 180, 320, 320
     nfr = sum(batches) + 1
     f = _stream(H, W, nfr)
@@ -56,6 +61,7 @@ def test_lookahead_matches_oracle(klt, ok, gpu_ctx, batches, device_frames, pinn
     val[7] = -1         # lost features stay untouched
     ref = _oracle_lists(ok, op, f, x, y, val)
 
+    gpu_ctx.set_coarse_split(split)
     la = klt.Lookahead(gpu_ctx, W, H, n, max(batches))
     dptr = [gpu_ctx.device_upload(a) for a in f] if device_frames else []
     outs = []
@@ -80,6 +86,7 @@ def test_lookahead_matches_oracle(klt, ok, gpu_ctx, batches, device_frames, pinn
         tracked_total, _ = la.flist.stats()
     finally:
         la.close()
+        gpu_ctx.set_coarse_split(0)
         for p in dptr:
             gpu_ctx.device_free(p)
     try:
