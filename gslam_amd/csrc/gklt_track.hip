@@ -509,6 +509,24 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
     }
   }
   // one patch element for all three planes / for the image plane only
+  // FRM: the interpolation from the lane's raw footprint texel.  The raw texels of the second image
+  // are kept between Newton iterations: an iteration that leaves the window in the same pixel cell
+  // (most after the first of a level: the steps are sub-pixel) changes the weights only, and costs
+  // no trip to memory -- the dependent load was the longest link of the per-feature chain.
+  auto frm3 = [&](const Texel &t, const Bilin &b) {
+    const float nx = from_next_lane(t.x), ny = from_next_lane(t.y), nz = from_next_lane(t.z);
+    const float bx = t.x * b.w2 + nx * b.w3, by = t.y * b.w2 + ny * b.w3, bz = t.z * b.w2 + nz * b.w3;
+    float3 o;
+    o.x = (t.x * b.w0 + nx * b.w1) + __shfl_down(bx, FW);
+    o.y = (t.y * b.w0 + ny * b.w1) + __shfl_down(by, FW);
+    o.z = (t.z * b.w0 + nz * b.w1) + __shfl_down(bz, FW);
+    return o;
+  };
+  auto frm1 = [&](float t, const Bilin &b) {
+    const float n = from_next_lane(t);
+    const float bl = t * b.w2 + n * b.w3;
+    return (t * b.w0 + n * b.w1) + __shfl_down(bl, FW);
+  };
   auto gather3 = [&](const Texel *__restrict__ p, int nc, const Bilin &b) {
     if constexpr (FRM) {
       const Texel t = *p;
@@ -762,6 +780,8 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
       clamp_origin(b2, hw, hh, nc, nr);
       const Texel *o2 = lt2 + (size_t)(b2.yt - hh) * nc + (b2.xt - hw);
       float3 T1[EPL], S2[EPL];
+      [[maybe_unused]] Texel R2{};           // FRM: the lane's raw texel of the second image ...
+      [[maybe_unused]] int cx2 = 0, cy2 = 0;  // ... and the pixel cell (clamped window origin) it was loaded for
       int X0 = 0, Y0 = 0;  // first texel of the second image's footprint in LDS
       // stages the footprint around window origin (wx, wy) unless the one in LDS covers it;
       // returns the origin's offset inside the footprint
@@ -789,6 +809,12 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
         fp_store(f2);
         __syncthreads();
         sample_all(b2, HL, HL, S2);
+      } else if constexpr (FRM) {
+        const Texel r1 = o1[eoff_y[0] * nc + eoff_x[0]];
+        R2 = o2[eoff_y[0] * nc + eoff_x[0]];  // both in flight together
+        cx2 = b2.xt; cy2 = b2.yt;
+        T1[0] = frm3(r1, b1);
+        S2[0] = frm3(R2, b2);
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) T1[e] = gather3(o1 + eoff_y[e] * nc + eoff_x[e], nc, b1);
@@ -838,6 +864,12 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           int ox, oy;
           stage2(b2.xt - hw, b2.yt - hh, ox, oy);
           sample_all(b2, ox, oy, S2);
+        } else if constexpr (FRM) {
+          if (b2.xt != cx2 || b2.yt != cy2) {  // wave-uniform
+            R2 = o2[eoff_y[0] * nc + eoff_x[0]];
+            cx2 = b2.xt; cy2 = b2.yt;
+          }
+          S2[0] = frm3(R2, b2);
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) S2[e] = gather3(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
@@ -857,6 +889,9 @@ __global__ __launch_bounds__(64) void k_track_w(TrackArgs a, TrackFrames F, Trac
           stage2(b2.xt - hw, b2.yt - hh, ox, oy);
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sI[e] = fp_sample(e, b2, ox, oy).x;
+        } else if constexpr (FRM) {
+          if (b2.xt != cx2 || b2.yt != cy2) R2.x = o2[eoff_y[0] * nc + eoff_x[0]].x;
+          sI[0] = frm1(R2.x, b2);
         } else {
 #pragma unroll
           for (int e = 0; e < EPL; ++e) sI[e] = gather1(o2 + eoff_y[e] * nc + eoff_x[e], nc, b2);
