@@ -1029,9 +1029,14 @@ WaveGeom wave_geom_compute(const gklt_ctx *ctx, int ww, int wh) {
   g.NA = 8 * ((ww * wh + 8) / 8);
   g.halo = g.run = 0;
   g.NF = (ww + 1) * (wh + 1);
-  // Footprint staging pays for large windows only (measured without / with staging: 7x7 18.1 /
-  // 19.2 us at C2, 11x11 86 / 98 us at C3, 21x21 67 / 39 us at Cship); track_impl 2 / 3 force it.
-  g.stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && ww * wh >= 200);
+  // Footprint staging for every window that does not fit the footprint-in-registers kernel
+  // ((w+1)(h+1) > 64); track_impl 2 / 3 force gathers / staging.  Rounds 1-2 staged windows of 200
+  // elements and more only (11x11 was 86 us with gathers, 98 us staged at C3); since the staged
+  // texels are read with ds_read_b128 (round 3) staging wins from 9x9 up in the lookahead pipeline,
+  // where the gathers compete with the build for the texture path -- gathers / staged, M
+  // feature-frames/s at the C3 geometry: 9x9 154 / 158, 11x11 145 / 154, 13x13 97 / 107
+  // (tools/exp_la_window.py); a single-frame launch alone is as fast either way.
+  g.stage = ctx->track_impl == 3 || (ctx->track_impl == 0 && (ww + 1) * (wh + 1) > 64);
   if (g.stage) {
     static const int env_halo = getenv("GKLT_TRACK_HALO") ? atoi(getenv("GKLT_TRACK_HALO")) : 0;
     g.halo = std::min(std::max(env_halo, 0), 4);
@@ -1240,12 +1245,10 @@ int launch_track_frames(gklt_ctx *ctx, hipStream_t s, const gklt_pyramid *const 
     // that takes more of the chip's wave slots for the length of a whole batch starves the pyramid
     // build it overlaps with (C3, 16000 features, lookahead 16: cap 4096 -> 117 M, 8192 -> 112 M,
     // uncapped -> 106 M feature-frames/s).  Single-frame launches are short and latency matters:
-    // one wavefront per feature.  Round 3, after the level kernels got faster: windows that do
-    // not fit the footprint-in-registers kernel (more than 64 footprint texels: 11 x 11 and up) do
-    // best at 6 wavefronts per SIMD (C3: 4096 -> 144.7 M, 6144 -> 151.8 M, 8192 -> 145.3 M), the
-    // 7 x 7 kernel stays at 4 (C2 unchanged up to 6144; 16 streams 196 M at 4096, 177 M at 6144):
-    // tools/sweep_waves.sh.
-    const int cap = g.frm ? 4096 : 6144;
+    // one wavefront per feature.  (Round 3, re-measured with the faster level kernels and the
+    // staged 11 x 11 kernel: C3 164.4 / 162.9 / 164.8 M at 4096 / 6144 / 8192, 16 streams of C2
+    // 196 M at 4096 and 177 M at 6144: tools/sweep_waves.sh.)
+    const int cap = 4096;
     const int nwaves = std::min(n, ctx->track_waves > 0 ? ctx->track_waves : (nframes > 1 ? cap : n));
     TrackFrames F{};
     F.nframes = nframes;

@@ -443,15 +443,15 @@ int gklt_device_mem_info(gklt_ctx *ctx, size_t *free_bytes, size_t *total_bytes)
 /* ---- measurement ---- */
 
 /* Tracker mapping: 0 = one feature per wavefront; sampling chosen by window size: footprint in
- * registers (footprint <= 64 texels, e.g. 7x7), four gathers per element, or LDS footprint staging
- * with a lane per window-row run (default); 1 = one feature per 8-lane slice; 2 / 3 = per wavefront
- * with gathers / with staging and a lane per element.
+ * registers (footprint <= 64 texels, e.g. 7x7), else the footprint staged in LDS (a lane per
+ * window-row run for windows 15..21 wide) (default); 1 = one feature per 8-lane slice; 2 / 3 = per
+ * wavefront with four gathers per element / with staging and a lane per element.
  * All produce identical results; selectable for A/B timing. */
 int gklt_ctx_set_track_impl(gklt_ctx *ctx, int impl);
 /* Wavefronts per wave-per-feature tracker launch; each takes features w, w + waves, ...  The
  * default (0) is one wavefront per feature for single-frame launches and, for the multi-frame
- * launches of the lookahead pipeline, a cap of 4096 wavefronts (4 per SIMD; 6144 for windows
- * of more than 64 footprint texels, e.g. 11 x 11), so that the pyramid build it overlaps with always finds room.
+ * launches of the lookahead pipeline, a cap of 4096 wavefronts (4 per SIMD), so that the pyramid
+ * build it overlaps with always finds room.
  * Results do not depend on it. */
 int gklt_ctx_set_track_waves(gklt_ctx *ctx, int waves);
 /* Pyramid build: 0 = one fused launch per level (u8 -> smooth -> texels + next level; 64 x 32
