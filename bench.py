@@ -1044,6 +1044,12 @@ def main(argv=None):
                      "algorithmic_bytes_per_launch": alg, "avg_launch_us": per_kernel[dom]["avg_us"],
                      "frames_per_launch": fpl, "frames_in_profiled_launches": psteps,
                      "profiled_launches": launches,
+                     # both kernels of the leg, whichever is the dominant one (at the driver's 20 steps
+                     # the tracker launch is, since round 3; in steady state the level-0 launch)
+                     "by_kernel": {names[k]: {"avg_launch_us": per_kernel[k]["avg_us"],
+                                              "achieved": alg_leg[k] / (per_kernel[k]["total_ms"] * 1e-3) / 1e9,
+                                              "frac": alg_leg[k] / (per_kernel[k]["total_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                   for k in alg_leg if k in per_kernel},
                      "level0_alone": ({"avg_launch_us": alone["level0"],
                                        "achieved": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9,
                                        "frac": alg_by_kernel["level0"] / (alone["level0"] * 1e-6) / 1e9 / HBM_PEAK_GBS,

@@ -262,6 +262,7 @@ struct FastGeom {
   static constexpr int NG = (O + 3 + 2 * R) / 4 + 1;  // float4 groups per 4-output window
   static constexpr int ROW_TASKS = IH * (TW / 4);
   static_assert(IWP <= 128 && IWP % 4 == 0, "two lane chunks per staged row");
+  static_assert(IH % 2 == 0, "row_of_task16 hands out rows in pairs");
 };
 
 template <int R, int SYM, int N>
@@ -537,6 +538,7 @@ struct LevelGeom {
   static constexpr int STRIPS = LNT / (AW / 2);    // column pass of level 0: strips per column pair
   static constexpr int SR = (IHh + STRIPS - 1) / STRIPS;
   static_assert(SW <= 128 && AW % 4 == 0, "two lane chunks per staged row");
+  static_assert(IHh % 2 == 0, "row_of_task16 hands out rows in pairs");
   static_assert(4 * NGA - 4 <= 2 * R0P && 60 + 4 * NGI <= AW, "row windows stay inside a row");
 };
 
