@@ -16,7 +16,7 @@ for f in glob.glob("gpurun_out/prof_c5_r3/trace/**/*memory_copy_trace.csv", recu
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "")))
 rows.sort()
-idx = [i for i, r in enumerate(rows) if "integral_rows" in r[2]]
+idx = [i for i, r in enumerate(rows) if r[2].startswith("k_score")]
 if not idx:
     print(sorted(set(r[2] for r in rows)))
 print("rows", len(rows), "selections", len(idx))
