@@ -1,6 +1,10 @@
 #!/bin/bash
 # LDS counters of the level kernels with one class of LDS access removed per build (tools/bin/libgklt_exp<K>.so,
 # outputs wrong, only the counters matter): which accesses the bank-conflict cycles belong to
+# (the variant builds were made from a scratch copy of gklt_pyramid.hip in which the reads / writes of one
+# phase of level_tile were replaced by register constants / made conditional on an impossible value, one
+# class per build: second row pass reads 1, its writes 2, gradient column reads 4, pyramid column reads 8,
+# centre pixel reads 16; they are not kept in the tree.  KS lists the variants present; 0 = the library)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/exp_lds_skip
