@@ -101,6 +101,17 @@ def test_lookahead_matches_oracle(klt, ok, gpu_ctx, batches, device_frames, pinn
                 gpu_ctx.pinned_free(p)
 
 
+@pytest.mark.parametrize("pyr_impl", [1, 2, 3])
+def test_lookahead_split_build_other_pyramid_kernels(klt, ok, gpu_ctx, pyr_impl):
+    """The second build stream with the unfused kernels (the whole build stays on the first stream
+    and the second one waits for it) and with the other fused variants: same lists."""
+    gpu_ctx.set_pyramid_impl(pyr_impl)
+    try:
+        test_lookahead_matches_oracle(klt, ok, gpu_ctx, [3, 4, 1, 3], True, True, 1)
+    finally:
+        gpu_ctx.set_pyramid_impl(0)
+
+
 def test_lookahead_reseed_between_batches(klt, ok, gpu_ctx):
     """upload_features() applies from the first frame that is submitted but not yet tracked."""
     H, W, n, B = 135, 240, 200, 3
