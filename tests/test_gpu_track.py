@@ -46,10 +46,11 @@ def _assert_same(got, ref):
 
 @pytest.mark.parametrize("window,levels,H,W,n", [
     (7, 4, 270, 480, 1000),     # C2 shape, reduced frame
-    (11, 3, 270, 480, 700),     # register path 11x11
-    (21, 2, 200, 320, 300),     # as-shipped window: generic LDS path
-    (5, 3, 135, 240, 333),      # generic path, n not a multiple of 8
-    (9, 2, 135, 240, 64),
+    (11, 3, 270, 480, 700),     # 11x11: LDS-staged footprint since round 3 (gathers: impl 2 below)
+    (21, 2, 200, 320, 300),     # as-shipped window: LDS-staged footprint, a lane per window-row run
+    (5, 3, 135, 240, 333),      # footprint in registers, n not a multiple of 8
+    (9, 2, 135, 240, 64),       # smallest staged window (10 x 10 footprint texels)
+    (13, 3, 200, 320, 260),     # staged, four window elements per lane
     (3, 2, 135, 240, 100),      # smallest window: footprint-in-registers sampling, 7 tail entries
     (31, 2, 200, 320, 40),      # 961 px: 16 window elements per lane
     (33, 1, 200, 320, 24),      # beyond the wave-per-feature kernel: slice kernel with LDS template
